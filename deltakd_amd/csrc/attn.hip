@@ -1,0 +1,356 @@
+// Scaled-dot-product attention forward / backward for ViT-sized sequences (N <= 256, head_dim 64) on gfx950.
+//
+// Replaces F.scaled_dot_product_attention inside timm's Attention ([3P], reached from model/models.py:195 of the
+// reference).  A whole head's K and V (<= 256 x 64 bf16) fit in LDS, so there is no online-softmax rescale: one
+// workgroup per (batch, head); each wave owns 16-query tiles.
+//
+// MFMA orientation (cdna_hip_programming section 3, "accumulator tile as the next MFMA's operand"): the score tile is
+// computed TRANSPOSED, S^T = K Q^T, so a lane owns one query (column = lane&15) and 4 keys per 16-key tile.  Row max / sum
+// are then 2 xor-shuffles (lanes +16, +32), and the probabilities feed the next product O^T = V^T P^T straight from the
+// accumulator registers as its B operand (k-slot permutation key(g,j) = 4g+j | 16+4g+(j-4), matched on the V side by two
+// ds_read_b64_tr_b16 hardware-transposed reads).  Nothing but K/V ever touches LDS.
+// The qkv operand is the packed output of the qkv Linear ([B, N, 3, H, 64]) read in place: no head-split copy.
+#include "common.h"
+
+namespace {
+
+constexpr int KV_LD = 160;  // bytes per LDS row: 128 B data + 32 B pad (b128 row reads and tr_b16 reads both conflict-free)
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float LN2 = 0.6931471805599453f;
+
+__device__ __forceinline__ bf16x8 tr_pair(const char* p) {
+  s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)LDS_PTR(p));
+  s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)LDS_PTR(p + 16 * KV_LD));
+  s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_bit_cast(bf16x8, v);
+}
+__device__ __forceinline__ bf16x8 pack8(const f32x4& a, const f32x4& b) {
+  typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+  u32x4 u = {pack2bf(a[0], a[1]), pack2bf(a[2], a[3]), pack2bf(b[0], b[1]), pack2bf(b[2], b[3])};
+  return __builtin_bit_cast(bf16x8, u);
+}
+__device__ __forceinline__ void store4bf(bf16_t* p, const f32x4& v, float s) {
+  uint2 pk = {pack2bf(v[0] * s, v[1] * s), pack2bf(v[2] * s, v[3] * s)};
+  *(uint2*)p = pk;
+}
+
+// stage `rows_valid` rows of 64 bf16 (row stride ld elements) into an LDS image of `rows_total` rows, zero padded
+__device__ __forceinline__ void stage_rows(char* dst, const bf16_t* src, int ld, int rows_valid, int rows_total, int tid) {
+  for (int idx = tid; idx < rows_total * 8; idx += 256) {
+    const int row = idx >> 3, ch = idx & 7;
+    s16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (row < rows_valid) v = *(const s16x8*)(src + (size_t)row * ld + ch * 8);
+    *(s16x8*)(dst + row * KV_LD + ch * 16) = v;
+  }
+}
+
+template <int NKT>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
+                                                       float* __restrict__ lse, int N, int H) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int i16 = lane & 15, fg = lane >> 4;
+  const int b = blockIdx.x / H, h = blockIdx.x % H;
+  const int D = H * 64, ld = 3 * D;
+  const bf16_t* base = qkv + (size_t)b * N * ld + h * 64;
+  char* Ks = smem;
+  char* Vs = smem + NKT * 16 * KV_LD;
+  stage_rows(Ks, base + D, ld, N, NKT * 16, tid);
+  stage_rows(Vs, base + 2 * D, ld, N, NKT * 16, tid);
+  __syncthreads();
+
+  const float c = 0.125f * LOG2E;
+  const int nqt = (N + 15) >> 4;
+  for (int qt = w; qt < nqt; qt += 4) {
+    const int q = qt * 16 + i16;
+    const int qc = q < N ? q : N - 1;
+    bf16x8 qf[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) qf[ks] = *(const bf16x8*)(base + (size_t)qc * ld + ks * 32 + 8 * fg);
+    f32x4 s[NKT];
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+      s[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const bf16x8 kf = *(const bf16x8*)(Ks + (kt * 16 + i16) * KV_LD + (ks * 32 + 8 * fg) * 2);
+        s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], s[kt], 0, 0, 0);
+      }
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = kt * 16 + 4 * fg + r;
+        const float v = key < N ? s[kt][r] * c : -INFINITY;
+        s[kt][r] = v;
+        mx = fmaxf(mx, v);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float p = __builtin_amdgcn_exp2f(s[kt][r] - mx);
+        s[kt][r] = p;
+        sum += p;
+      }
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+
+    f32x4 o[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kp = 0; kp < NKT / 2; ++kp) {
+      const bf16x8 pf = pack8(s[2 * kp], s[2 * kp + 1]);
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        const bf16x8 vf = tr_pair(Vs + (32 * kp + 4 * fg + (i16 >> 2)) * KV_LD + (dt * 16 + 4 * (i16 & 3)) * 2);
+        o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, o[dt], 0, 0, 0);
+      }
+    }
+    if (q < N) {
+      const float inv = 1.f / sum;
+      bf16_t* op = out + ((size_t)b * N + q) * D + h * 64 + 4 * fg;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) store4bf(op + dt * 16, o[dt], inv);
+      if (lse && fg == 0) lse[((size_t)b * H + h) * N + q] = mx * LN2 + __logf(sum);
+    }
+  }
+}
+
+// dQ: waves own query tiles; K (row + transposed reads) and V (row reads) in LDS.
+template <int NKT>
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out,
+                                                          const bf16_t* __restrict__ dout, const float* __restrict__ lse,
+                                                          bf16_t* __restrict__ dqkv, int N, int H) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int i16 = lane & 15, fg = lane >> 4;
+  const int b = blockIdx.x / H, h = blockIdx.x % H;
+  const int D = H * 64, ld = 3 * D;
+  const bf16_t* base = qkv + (size_t)b * N * ld + h * 64;
+  char* Ks = smem;
+  char* Vs = smem + NKT * 16 * KV_LD;
+  stage_rows(Ks, base + D, ld, N, NKT * 16, tid);
+  stage_rows(Vs, base + 2 * D, ld, N, NKT * 16, tid);
+  __syncthreads();
+
+  const float c = 0.125f * LOG2E;
+  const int nqt = (N + 15) >> 4;
+  for (int qt = w; qt < nqt; qt += 4) {
+    const int q = qt * 16 + i16;
+    const int qc = q < N ? q : N - 1;
+    const size_t orow = ((size_t)b * N + qc) * D + h * 64;
+    bf16x8 qf[2], dof[2];
+    float delta = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      qf[ks] = *(const bf16x8*)(base + (size_t)qc * ld + ks * 32 + 8 * fg);
+      dof[ks] = *(const bf16x8*)(dout + orow + ks * 32 + 8 * fg);
+      const bf16x8 of = *(const bf16x8*)(out + orow + ks * 32 + 8 * fg);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) delta += (float)dof[ks][e] * (float)of[e];
+    }
+    delta += __shfl_xor(delta, 16, 64);
+    delta += __shfl_xor(delta, 32, 64);
+    const float lq = lse[((size_t)b * H + h) * N + qc] * LOG2E;
+
+    f32x4 ds[NKT];
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+      f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const int off = (kt * 16 + i16) * KV_LD + (ks * 32 + 8 * fg) * 2;
+        s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)(Ks + off), qf[ks], s, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)(Vs + off), dof[ks], dp, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = kt * 16 + 4 * fg + r;
+        const float p = key < N ? __builtin_amdgcn_exp2f(s[r] * c - lq) : 0.f;
+        ds[kt][r] = p * (dp[r] - delta) * 0.125f;
+      }
+    }
+    f32x4 dq[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kp = 0; kp < NKT / 2; ++kp) {
+      const bf16x8 dsf = pack8(ds[2 * kp], ds[2 * kp + 1]);
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        const bf16x8 ktf = tr_pair(Ks + (32 * kp + 4 * fg + (i16 >> 2)) * KV_LD + (dt * 16 + 4 * (i16 & 3)) * 2);
+        dq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktf, dsf, dq[dt], 0, 0, 0);
+      }
+    }
+    if (q < N) {
+      bf16_t* dp_ = dqkv + ((size_t)b * N + q) * ld + h * 64 + 4 * fg;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) store4bf(dp_ + dt * 16, dq[dt], 1.f);
+    }
+  }
+}
+
+// dK, dV: waves own key tiles; Q and dO (row + transposed reads), lse and delta in LDS.
+template <int NQT>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out,
+                                                           const bf16_t* __restrict__ dout, const float* __restrict__ lse,
+                                                           bf16_t* __restrict__ dqkv, int N, int H) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int i16 = lane & 15, fg = lane >> 4;
+  const int b = blockIdx.x / H, h = blockIdx.x % H;
+  const int D = H * 64, ld = 3 * D;
+  const bf16_t* base = qkv + (size_t)b * N * ld + h * 64;
+  const bf16_t* obase = out + (size_t)b * N * D + h * 64;
+  const bf16_t* dobase = dout + (size_t)b * N * D + h * 64;
+  char* Qs = smem;
+  char* dOs = smem + NQT * 16 * KV_LD;
+  float* lse_s = (float*)(smem + 2 * NQT * 16 * KV_LD);
+  float* dl_s = lse_s + NQT * 16;
+  stage_rows(Qs, base, ld, N, NQT * 16, tid);
+  stage_rows(dOs, dobase, D, N, NQT * 16, tid);
+  __syncthreads();
+  if (tid < NQT * 16) {
+    float d = 0.f, l = 0.f;
+    if (tid < N) {
+#pragma unroll
+      for (int ch = 0; ch < 8; ++ch) {
+        const bf16x8 ov = *(const bf16x8*)(obase + (size_t)tid * D + ch * 8);
+        const bf16x8 dv = *(const bf16x8*)(dOs + tid * KV_LD + ch * 16);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) d += (float)ov[e] * (float)dv[e];
+      }
+      l = lse[((size_t)b * H + h) * N + tid] * LOG2E;
+    }
+    dl_s[tid] = d;
+    lse_s[tid] = l;
+  }
+  __syncthreads();
+
+  const float c = 0.125f * LOG2E;
+  const int nkt = (N + 15) >> 4;
+  for (int kt = w; kt < nkt; kt += 4) {
+    const int key = kt * 16 + i16;
+    const int kc = key < N ? key : N - 1;
+    bf16x8 kf[2], vf[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      kf[ks] = *(const bf16x8*)(base + (size_t)kc * ld + D + ks * 32 + 8 * fg);
+      vf[ks] = *(const bf16x8*)(base + (size_t)kc * ld + 2 * D + ks * 32 + 8 * fg);
+    }
+    f32x4 dk[4], dv[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      dk[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      dv[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll 1
+    for (int qp = 0; qp < NQT / 2; ++qp) {
+      f32x4 pp[2], dss[2];
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {
+        const int qt = 2 * qp + hf;
+        f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          const int off = (qt * 16 + i16) * KV_LD + (ks * 32 + 8 * fg) * 2;
+          s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)(Qs + off), kf[ks], s, 0, 0, 0);
+          dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)(dOs + off), vf[ks], dp, 0, 0, 0);
+        }
+        const f32x4 lq = *(const f32x4*)&lse_s[qt * 16 + 4 * fg];
+        const f32x4 dl = *(const f32x4*)&dl_s[qt * 16 + 4 * fg];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float p = __builtin_amdgcn_exp2f(s[r] * c - lq[r]);
+          pp[hf][r] = p;
+          dss[hf][r] = p * (dp[r] - dl[r]) * 0.125f;
+        }
+      }
+      const bf16x8 pf = pack8(pp[0], pp[1]);
+      const bf16x8 dsf = pack8(dss[0], dss[1]);
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        const int off = (32 * qp + 4 * fg + (i16 >> 2)) * KV_LD + (dt * 16 + 4 * (i16 & 3)) * 2;
+        dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_pair(dOs + off), pf, dv[dt], 0, 0, 0);
+        dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_pair(Qs + off), dsf, dk[dt], 0, 0, 0);
+      }
+    }
+    if (key < N) {
+      bf16_t* kp_ = dqkv + ((size_t)b * N + key) * ld + D + h * 64 + 4 * fg;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        store4bf(kp_ + dt * 16, dk[dt], 1.f);
+        store4bf(kp_ + D + dt * 16, dv[dt], 1.f);
+      }
+    }
+  }
+}
+
+template <typename K>
+int set_smem(K kernel, int bytes) {
+  if (bytes <= 65536) return 0;
+  hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e != hipSuccess) {
+    dkd_set_error("attention: cannot raise dynamic LDS to %d bytes: %s", bytes, hipGetErrorString(e));
+    return DKD_ERR_HIP;
+  }
+  return 0;
+}
+
+#define DISPATCH_NT(NT, CALL)                         \
+  switch (NT) {                                       \
+    case 2: { constexpr int T = 2; CALL; } break;     \
+    case 4: { constexpr int T = 4; CALL; } break;     \
+    case 8: { constexpr int T = 8; CALL; } break;     \
+    case 14: { constexpr int T = 14; CALL; } break;   \
+    default: { constexpr int T = 16; CALL; } break;   \
+  }
+
+int pick_tiles(int N) {
+  const int need = (N + 15) / 16;
+  const int opts[5] = {2, 4, 8, 14, 16};
+  for (int i = 0; i < 5; ++i)
+    if (opts[i] >= need) return opts[i];
+  return -1;
+}
+
+}  // namespace
+
+extern "C" int dkd_attn_fwd(const void* qkv, void* out, float* lse, int32_t B, int32_t N, int32_t H, void* stream) {
+  DKD_CHECK_ARG(qkv && out, "attn_fwd: null operand");
+  DKD_CHECK_ARG(B > 0 && H > 0 && N > 0 && N <= 256, "attn_fwd: need 0 < N <= 256 (got N=%d B=%d H=%d)", N, B, H);
+  const int nt = pick_tiles(N);
+  const int smem = 2 * nt * 16 * KV_LD;
+  DISPATCH_NT(nt, {
+    if (int rc = set_smem(attn_fwd_kernel<T>, smem)) return rc;
+    hipLaunchKernelGGL(attn_fwd_kernel<T>, dim3(B * H), dim3(256), smem, as_stream(stream), (const bf16_t*)qkv, (bf16_t*)out, lse, N, H);
+  });
+  DKD_CHECK_LAUNCH("attn_fwd");
+  return DKD_OK;
+}
+
+extern "C" int dkd_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, int32_t B, int32_t N,
+                            int32_t H, void* stream) {
+  DKD_CHECK_ARG(qkv && out && dout && lse && dqkv, "attn_bwd: null operand");
+  DKD_CHECK_ARG(B > 0 && H > 0 && N > 0 && N <= 256, "attn_bwd: need 0 < N <= 256 (got N=%d)", N);
+  const int nt = pick_tiles(N);
+  const int smem1 = 2 * nt * 16 * KV_LD;
+  const int smem2 = smem1 + 2 * nt * 16 * 4;
+  DISPATCH_NT(nt, {
+    if (int rc = set_smem(attn_bwd_dq_kernel<T>, smem1)) return rc;
+    if (int rc = set_smem(attn_bwd_dkv_kernel<T>, smem2)) return rc;
+    hipLaunchKernelGGL(attn_bwd_dq_kernel<T>, dim3(B * H), dim3(256), smem1, as_stream(stream), (const bf16_t*)qkv, (const bf16_t*)out,
+                       (const bf16_t*)dout, lse, (bf16_t*)dqkv, N, H);
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel<T>, dim3(B * H), dim3(256), smem2, as_stream(stream), (const bf16_t*)qkv, (const bf16_t*)out,
+                       (const bf16_t*)dout, lse, (bf16_t*)dqkv, N, H);
+  });
+  DKD_CHECK_LAUNCH("attn_bwd");
+  return DKD_OK;
+}

@@ -1,0 +1,68 @@
+// Shared device/host helpers for libdkd (gfx950 only: wave64, MFMA, LDS-DMA).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/dkd.h"
+
+typedef uint16_t bf16_t;  // raw bf16 payload
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+#define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+#define GLB_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
+
+void dkd_set_error(const char* fmt, ...);
+
+#define DKD_CHECK_ARG(cond, ...)                \
+  do {                                          \
+    if (!(cond)) {                              \
+      dkd_set_error(__VA_ARGS__);               \
+      return DKD_ERR_ARG;                       \
+    }                                           \
+  } while (0)
+
+#define DKD_CHECK_LAUNCH(name)                                                   \
+  do {                                                                           \
+    hipError_t e_ = hipGetLastError();                                           \
+    if (e_ != hipSuccess) {                                                      \
+      dkd_set_error("%s: launch failed: %s", name, hipGetErrorString(e_));       \
+      return DKD_ERR_HIP;                                                        \
+    }                                                                            \
+  } while (0)
+
+__device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+
+// round-to-nearest-even f32 -> bf16 (plain cast: v_cvt_pk_bf16_f32, NaN stays NaN)
+__device__ __forceinline__ bf16_t f2bf(float f) {
+  __bf16 b = (__bf16)f;
+  return __builtin_bit_cast(bf16_t, b);
+}
+__device__ __forceinline__ uint32_t pack2bf(float lo, float hi) { return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16); }
+
+__device__ __forceinline__ int map_row(const DkdRowMap& m, int r) {
+  return m.rpg > 0 ? (r / m.rpg) * m.gstride + (r % m.rpg) + m.off : r;
+}
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float dgelu_erf(float x) {
+  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
+  const float pdf = 0.3989422804014327f * __expf(-0.5f * x * x);
+  return cdf + x * pdf;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+static inline hipStream_t as_stream(void* s) { return (hipStream_t)s; }
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }

@@ -1,0 +1,208 @@
+// HBM-bound data-movement kernels around the GEMMs: patch gather, token assembly, casts, column sums, AdamW.
+// All use 16-byte accesses per lane where the layout allows (cdna_hip_programming Guideline 13).
+#include "common.h"
+
+namespace {
+
+// img f32 [B, C, H, W] -> patches bf16 [B*gh*gw, C*p*p], k = c*p*p + i*p + j (Conv2d weight order).
+// One thread handles 4 consecutive j (16-B read, 8-B write).
+__global__ void im2col_kernel(const float* __restrict__ img, bf16_t* __restrict__ out, int B, int C, int H, int W, int p, long total4) {
+  const int gw = W / p, gh = H / p, K = C * p * p;
+  for (long t = blockIdx.x * (long)blockDim.x + threadIdx.x; t < total4; t += (long)gridDim.x * blockDim.x) {
+    const long e = t * 4;
+    const int k = (int)(e % K);
+    const long row = e / K;
+    const int j = k % p, i = (k / p) % p, c = k / (p * p);
+    const int px = (int)(row % gw), py = (int)((row / gw) % gh), b = (int)(row / ((long)gw * gh));
+    const float* src = img + (((size_t)b * C + c) * H + (py * p + i)) * W + px * p + j;
+    const f32x4 v = *(const f32x4*)src;
+    uint2 pk = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+    *(uint2*)(out + e) = pk;
+  }
+}
+
+__global__ void prefix_tokens_kernel(float* __restrict__ x, const float* __restrict__ tok, const float* __restrict__ pos, int B, int N, int D, int npre) {
+  const int total = B * npre * D;
+  for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += gridDim.x * blockDim.x) {
+    const int d = t % D, tk = (t / D) % npre, b = t / (D * npre);
+    x[((size_t)b * N + tk) * D + d] = tok[tk * D + d] + pos[tk * D + d];
+  }
+}
+
+// dpos[t, d] += sum_b dx[b, t, d]; dtok[t, d] += same for t < npre.  grid = (N, splits over B)
+__global__ void embed_bwd_kernel(const float* __restrict__ dx, float* __restrict__ dtok, float* __restrict__ dpos, int B, int N, int D, int npre) {
+  const int t = blockIdx.x;
+  const int b0 = blockIdx.y * 32, b1 = min(B, b0 + 32);
+  for (int d = threadIdx.x; d < D; d += blockDim.x) {
+    float s = 0.f;
+    for (int b = b0; b < b1; ++b) s += dx[((size_t)b * N + t) * D + d];
+    atomicAdd(&dpos[t * D + d], s);
+    if (t < npre) atomicAdd(&dtok[t * D + d], s);
+  }
+}
+
+__global__ void scale_cast_kernel(const float* __restrict__ x, int ldx, DkdRowMap xmap, const float* __restrict__ rowscale, int rps,
+                                  const float* __restrict__ add, int ldadd, bf16_t* __restrict__ y, int ldy, int M, int D) {
+  const int nv = D >> 2;
+  const long total = (long)M * nv;
+  for (long t = blockIdx.x * (long)blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+    const int m = (int)(t / nv), c = (int)(t % nv) * 4;
+    f32x4 v = *(const f32x4*)(x + (size_t)map_row(xmap, m) * ldx + c);
+    if (rowscale) v *= rowscale[m / rps];
+    if (add) v += *(const f32x4*)(add + (size_t)m * ldadd + c);
+    uint2 pk = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+    *(uint2*)(y + (size_t)m * ldy + c) = pk;
+  }
+}
+
+// w f32 [rows, cols] -> bf16 [rows, cols] and (optional) bf16 [cols, rows]; 32x32 tiles through LDS.
+__global__ void cast_weight_kernel(const float* __restrict__ w, bf16_t* __restrict__ wb, bf16_t* __restrict__ wt, int rows, int cols) {
+  __shared__ bf16_t tile[32][33];
+  const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 256 threads: 8 rows per pass
+  for (int i = ty; i < 32; i += 8) {
+    const int r = r0 + i, c = c0 + tx;
+    if (r < rows && c < cols) {
+      const bf16_t h = f2bf(w[(size_t)r * cols + c]);
+      if (wb) wb[(size_t)r * cols + c] = h;
+      tile[i][tx] = h;
+    }
+  }
+  if (!wt) return;
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8) {
+    const int c = c0 + i, r = r0 + tx;
+    if (r < rows && c < cols) wt[(size_t)c * rows + r] = tile[tx][i];
+  }
+}
+
+// out[n] += sum_m x[xmap(m), n]   grid = (ceil(N/64), row splits); block 256 = 4 row-lanes x 64 columns
+template <bool X_F32>
+__global__ void colsum_kernel(const void* __restrict__ x, int ldx, DkdRowMap xmap, float* __restrict__ out, int M, int N, int rows_per_block) {
+  __shared__ float red[4][64];
+  const int n = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+  const int m0 = blockIdx.y * rows_per_block, m1 = min(M, m0 + rows_per_block);
+  float s = 0.f;
+  if (n < N)
+    for (int m = m0 + rl; m < m1; m += 4) {
+      const size_t off = (size_t)map_row(xmap, m) * ldx + n;
+      s += X_F32 ? ((const float*)x)[off] : bf2f(((const bf16_t*)x)[off]);
+    }
+  red[rl][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (rl == 0 && n < N) atomicAdd(&out[n], red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+template <bool X_F32>
+__global__ void add_rows_kernel(const void* __restrict__ x, int ldx, float* __restrict__ y, int ldy, DkdRowMap ymap, int M, int D, int accumulate) {
+  const long total = (long)M * D;
+  for (long t = blockIdx.x * (long)blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+    const int m = (int)(t / D), d = (int)(t % D);
+    const float v = X_F32 ? ((const float*)x)[(size_t)m * ldx + d] : bf2f(((const bf16_t*)x)[(size_t)m * ldx + d]);
+    float* yp = y + (size_t)map_row(ymap, m) * ldy + d;
+    *yp = accumulate ? *yp + v : v;
+  }
+}
+
+__global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                             bf16_t* __restrict__ pb, long n, float lr, float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt,
+                             float gscale) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float gi = g[i] * gscale;
+    float pi = p[i] * (1.f - lr * wd);
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    pi -= (lr / bc1) * (mi / denom);
+    p[i] = pi;
+    if (pb) pb[i] = f2bf(pi);
+  }
+}
+
+inline int grid_for(long work, int block = 256, int cap = 4096) {
+  long g = (work + block - 1) / block;
+  return (int)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+}  // namespace
+
+extern "C" int dkd_im2col_patches(const float* img, void* patches, int32_t B, int32_t C, int32_t H, int32_t W, int32_t p, void* stream) {
+  DKD_CHECK_ARG(img && patches, "im2col: null operand");
+  DKD_CHECK_ARG(p % 4 == 0 && H % p == 0 && W % p == 0, "im2col: patch %d must divide %dx%d and be a multiple of 4", p, H, W);
+  const long total4 = (long)B * C * H * W / 4;
+  hipLaunchKernelGGL(im2col_kernel, dim3(grid_for(total4)), dim3(256), 0, as_stream(stream), img, (bf16_t*)patches, B, C, H, W, p, total4);
+  DKD_CHECK_LAUNCH("im2col");
+  return DKD_OK;
+}
+
+extern "C" int dkd_prefix_tokens_fwd(float* x, const float* tok, const float* pos, int32_t B, int32_t N, int32_t D, int32_t npre, void* stream) {
+  DKD_CHECK_ARG(x && tok && pos && npre > 0 && npre <= N, "prefix_tokens: bad arguments");
+  hipLaunchKernelGGL(prefix_tokens_kernel, dim3(grid_for((long)B * npre * D)), dim3(256), 0, as_stream(stream), x, tok, pos, B, N, D, npre);
+  DKD_CHECK_LAUNCH("prefix_tokens");
+  return DKD_OK;
+}
+
+extern "C" int dkd_embed_bwd(const float* dx, float* dtok, float* dpos, int32_t B, int32_t N, int32_t D, int32_t npre, void* stream) {
+  DKD_CHECK_ARG(dx && dtok && dpos, "embed_bwd: null operand");
+  hipLaunchKernelGGL(embed_bwd_kernel, dim3(N, cdiv(B, 32)), dim3(256), 0, as_stream(stream), dx, dtok, dpos, B, N, D, npre);
+  DKD_CHECK_LAUNCH("embed_bwd");
+  return DKD_OK;
+}
+
+extern "C" int dkd_scale_cast_bf16(const float* x, int32_t ldx, DkdRowMap xmap, const float* rowscale, int32_t rows_per_sample,
+                                   const float* add, int32_t ldadd, void* y, int32_t ldy, int32_t M, int32_t D, void* stream) {
+  DKD_CHECK_ARG(x && y, "scale_cast: null operand");
+  DKD_CHECK_ARG(D % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && (!add || ldadd % 4 == 0), "scale_cast: D/ld must be multiples of 4");
+  DKD_CHECK_ARG(!rowscale || rows_per_sample > 0, "scale_cast: rowscale needs rows_per_sample");
+  hipLaunchKernelGGL(scale_cast_kernel, dim3(grid_for((long)M * D / 4)), dim3(256), 0, as_stream(stream), x, ldx, xmap, rowscale,
+                     rows_per_sample, add, ldadd, (bf16_t*)y, ldy, M, D);
+  DKD_CHECK_LAUNCH("scale_cast");
+  return DKD_OK;
+}
+
+extern "C" int dkd_cast_weight(const float* w, void* w_bf16, void* w_t_bf16, int32_t rows, int32_t cols, void* stream) {
+  DKD_CHECK_ARG(w && (w_bf16 || w_t_bf16) && rows > 0 && cols > 0, "cast_weight: bad arguments");
+  hipLaunchKernelGGL(cast_weight_kernel, dim3(cdiv(cols, 32), cdiv(rows, 32)), dim3(256), 0, as_stream(stream), w, (bf16_t*)w_bf16,
+                     (bf16_t*)w_t_bf16, rows, cols);
+  DKD_CHECK_LAUNCH("cast_weight");
+  return DKD_OK;
+}
+
+extern "C" int dkd_colsum(const void* x, int32_t x_is_f32, int32_t ldx, DkdRowMap xmap, float* out, int32_t M, int32_t N, void* stream) {
+  DKD_CHECK_ARG(x && out && M > 0 && N > 0, "colsum: bad arguments");
+  const int col_blocks = cdiv(N, 64);
+  int splits = cdiv(1024, col_blocks);
+  if (splits > cdiv(M, 64)) splits = cdiv(M, 64);
+  const int rpb = cdiv(M, splits);
+  splits = cdiv(M, rpb);
+  if (x_is_f32)
+    hipLaunchKernelGGL(colsum_kernel<true>, dim3(col_blocks, splits), dim3(256), 0, as_stream(stream), x, ldx, xmap, out, M, N, rpb);
+  else
+    hipLaunchKernelGGL(colsum_kernel<false>, dim3(col_blocks, splits), dim3(256), 0, as_stream(stream), x, ldx, xmap, out, M, N, rpb);
+  DKD_CHECK_LAUNCH("colsum");
+  return DKD_OK;
+}
+
+extern "C" int dkd_add_rows(const void* x, int32_t x_is_f32, int32_t ldx, float* y, int32_t ldy, DkdRowMap ymap, int32_t M, int32_t D,
+                            int32_t accumulate, void* stream) {
+  DKD_CHECK_ARG(x && y && M > 0 && D > 0, "add_rows: bad arguments");
+  if (x_is_f32)
+    hipLaunchKernelGGL(add_rows_kernel<true>, dim3(grid_for((long)M * D)), dim3(256), 0, as_stream(stream), x, ldx, y, ldy, ymap, M, D, accumulate);
+  else
+    hipLaunchKernelGGL(add_rows_kernel<false>, dim3(grid_for((long)M * D)), dim3(256), 0, as_stream(stream), x, ldx, y, ldy, ymap, M, D, accumulate);
+  DKD_CHECK_LAUNCH("add_rows");
+  return DKD_OK;
+}
+
+extern "C" int dkd_adamw_step(float* p, const float* g, float* m, float* v, void* p_bf16, int64_t n, float lr, float beta1, float beta2,
+                              float eps, float weight_decay, int32_t step, float grad_scale, void* stream) {
+  DKD_CHECK_ARG(p && g && m && v && n > 0 && step > 0, "adamw: bad arguments");
+  const float bc1 = 1.f - powf(beta1, (float)step);
+  const float bc2s = sqrtf(1.f - powf(beta2, (float)step));
+  hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n, 256, 8192)), dim3(256), 0, as_stream(stream), p, g, m, v, (bf16_t*)p_bf16, (long)n, lr, beta1,
+                     beta2, eps, weight_decay, bc1, bc2s, grad_scale);
+  DKD_CHECK_LAUNCH("adamw");
+  return DKD_OK;
+}

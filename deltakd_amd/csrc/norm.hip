@@ -1,0 +1,170 @@
+// LayerNorm forward / backward (HBM-bound; one wave per row, 16-B accesses).
+// Replaces nn.LayerNorm(eps=1e-6) inside timm's Block ([3P], reached from model/models.py:195 of the reference).
+#include "common.h"
+
+namespace {
+
+constexpr int MAXV = 4;  // float4 vectors per lane: D <= 64 * 4 * MAXV = 1024
+
+template <bool OUT_F32>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, int ldx, DkdRowMap xmap, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, void* __restrict__ y, float* __restrict__ mean,
+                                                     float* __restrict__ rstd, int M, int D, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const float* xr = x + (size_t)map_row(xmap, row) * ldx;
+  const int nv = D >> 2;
+  f32x4 v[MAXV];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = lane + 64 * i;
+    v[i] = c < nv ? *(const f32x4*)(xr + 4 * c) : f32x4{0.f, 0.f, 0.f, 0.f};
+    s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+  }
+  const float mu = wave_sum(s) / D;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nv) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float d = v[i][e] - mu;
+        q += d * d;
+      }
+    }
+  }
+  const float rs = rsqrtf(wave_sum(q) / D + eps);
+  if (lane == 0) {
+    if (mean) mean[row] = mu;
+    if (rstd) rstd[row] = rs;
+  }
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nv) {
+      const f32x4 g = *(const f32x4*)(gamma + 4 * c), bb = *(const f32x4*)(beta + 4 * c);
+      f32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mu) * rs * g[e] + bb[e];
+      if (OUT_F32) *(f32x4*)((float*)y + (size_t)row * D + 4 * c) = o;
+      else {
+        uint2 pk = {pack2bf(o[0], o[1]), pack2bf(o[2], o[3])};
+        *(uint2*)((bf16_t*)y + (size_t)row * D + 4 * c) = pk;
+      }
+    }
+  }
+}
+
+// Each block walks ROWS_PER_BLOCK rows (4 waves x rows), keeps per-column dgamma/dbeta partials in registers, combines the
+// 4 waves through LDS and issues one f32 atomic per column per block.
+constexpr int LNB_ROWS = 64;
+template <bool DY_F32>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy, const float* __restrict__ x, int ldx, DkdRowMap xmap,
+                                                     const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                     const float* __restrict__ rstd, float* __restrict__ dx, int lddx, DkdRowMap dxmap,
+                                                     int accumulate, float* __restrict__ dgamma, float* __restrict__ dbeta, int M, int D) {
+  __shared__ float red[2][4][1024];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int nv = D >> 2;
+  f32x4 g[MAXV], ag[MAXV], ab[MAXV];
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = lane + 64 * i;
+    g[i] = c < nv ? *(const f32x4*)(gamma + 4 * c) : f32x4{0.f, 0.f, 0.f, 0.f};
+    ag[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    ab[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  const int r0 = blockIdx.x * LNB_ROWS;
+  for (int rr = w; rr < LNB_ROWS; rr += 4) {
+    const int row = r0 + rr;
+    if (row >= M) break;
+    const float* xr = x + (size_t)map_row(xmap, row) * ldx;
+    const float mu = mean[row], rs = rstd[row];
+    f32x4 xh[MAXV], gy[MAXV];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      const int c = lane + 64 * i;
+      xh[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      gy[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (c < nv) {
+        const f32x4 xv = *(const f32x4*)(xr + 4 * c);
+        f32x4 d;
+        if (DY_F32) d = *(const f32x4*)((const float*)dy + (size_t)row * D + 4 * c);
+        else {
+          const uint2 pk = *(const uint2*)((const bf16_t*)dy + (size_t)row * D + 4 * c);
+          d = f32x4{__uint_as_float(pk.x << 16), __uint_as_float(pk.x & 0xffff0000u), __uint_as_float(pk.y << 16),
+                    __uint_as_float(pk.y & 0xffff0000u)};
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          xh[i][e] = (xv[e] - mu) * rs;
+          ab[i][e] += d[e];
+          ag[i][e] += d[e] * xh[i][e];
+          gy[i][e] = d[e] * g[i][e];
+          s1 += gy[i][e];
+          s2 += gy[i][e] * xh[i][e];
+        }
+      }
+    }
+    s1 = wave_sum(s1) / D;
+    s2 = wave_sum(s2) / D;
+    float* dr = dx + (size_t)map_row(dxmap, row) * lddx;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nv) {
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = rs * (gy[i][e] - s1 - xh[i][e] * s2);
+        if (accumulate) o += *(const f32x4*)(dr + 4 * c);
+        *(f32x4*)(dr + 4 * c) = o;
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nv) {
+      *(f32x4*)&red[0][w][4 * c] = ag[i];
+      *(f32x4*)&red[1][w][4 * c] = ab[i];
+    }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < D; c += 256) {
+    atomicAdd(&dgamma[c], red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c]);
+    atomicAdd(&dbeta[c], red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c]);
+  }
+}
+
+}  // namespace
+
+extern "C" int dkd_layernorm_fwd(const float* x, int32_t ldx, DkdRowMap xmap, const float* gamma, const float* beta, void* y,
+                                 float* mean, float* rstd, int32_t M, int32_t D, float eps, int32_t y_is_f32, void* stream) {
+  DKD_CHECK_ARG(x && gamma && beta && y, "layernorm_fwd: null operand");
+  DKD_CHECK_ARG(M > 0 && D > 0 && D % 4 == 0 && D <= 1024 && ldx % 4 == 0, "layernorm_fwd: need D %% 4 == 0, D <= 1024 (D=%d ldx=%d)", D, ldx);
+  if (y_is_f32)
+    hipLaunchKernelGGL(ln_fwd_kernel<true>, dim3(cdiv(M, 4)), dim3(256), 0, as_stream(stream), x, ldx, xmap, gamma, beta, y, mean, rstd, M, D, eps);
+  else
+    hipLaunchKernelGGL(ln_fwd_kernel<false>, dim3(cdiv(M, 4)), dim3(256), 0, as_stream(stream), x, ldx, xmap, gamma, beta, y, mean, rstd, M, D, eps);
+  DKD_CHECK_LAUNCH("layernorm_fwd");
+  return DKD_OK;
+}
+
+extern "C" int dkd_layernorm_bwd(const void* dy, int32_t dy_is_f32, const float* x, int32_t ldx, DkdRowMap xmap, const float* gamma,
+                                 const float* mean, const float* rstd, float* dx, int32_t lddx, DkdRowMap dxmap, int32_t accumulate,
+                                 float* dgamma, float* dbeta, int32_t M, int32_t D, void* stream) {
+  DKD_CHECK_ARG(dy && x && gamma && mean && rstd && dx && dgamma && dbeta, "layernorm_bwd: null operand");
+  DKD_CHECK_ARG(M > 0 && D > 0 && D % 4 == 0 && D <= 1024 && ldx % 4 == 0 && lddx % 4 == 0, "layernorm_bwd: bad D=%d", D);
+  if (dy_is_f32)
+    hipLaunchKernelGGL(ln_bwd_kernel<true>, dim3(cdiv(M, LNB_ROWS)), dim3(256), 0, as_stream(stream), dy, x, ldx, xmap, gamma, mean, rstd, dx,
+                       lddx, dxmap, accumulate, dgamma, dbeta, M, D);
+  else
+    hipLaunchKernelGGL(ln_bwd_kernel<false>, dim3(cdiv(M, LNB_ROWS)), dim3(256), 0, as_stream(stream), dy, x, ldx, xmap, gamma, mean, rstd, dx,
+                       lddx, dxmap, accumulate, dgamma, dbeta, M, D);
+  DKD_CHECK_LAUNCH("layernorm_bwd");
+  return DKD_OK;
+}

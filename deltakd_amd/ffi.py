@@ -1,0 +1,122 @@
+"""ctypes binding of libdkd.so (C ABI: include/dkd.h).
+
+The library is the product: there is NO fallback.  ``lib()`` raises if the shared object is missing, and every wrapper
+raises if handed a non-GPU tensor -- a silent eager/CPU path would void every parity claim.
+"""
+import ctypes as C
+import os
+import threading
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libdkd.so")
+
+EPI_BIAS, EPI_GELU, EPI_DGELU, EPI_RESID = 1, 2, 4, 8
+EPI_OUT_F32, EPI_TAP_F32, EPI_RELU, EPI_ACCUM = 16, 32, 64, 128
+
+
+class RowMap(C.Structure):
+    _fields_ = [("rpg", C.c_int32), ("gstride", C.c_int32), ("off", C.c_int32)]
+
+
+IDENT = RowMap(0, 0, 0)
+
+
+def strip_map(tokens_per_sample: int, n_prefix: int) -> RowMap:
+    """rows of x[:, n_prefix:] viewed as [B*(tokens-n_prefix), D] inside a contiguous [B*tokens, D] buffer."""
+    return RowMap(tokens_per_sample - n_prefix, tokens_per_sample, n_prefix)
+
+
+class Gemm(C.Structure):
+    _fields_ = [
+        ("A", C.c_void_p), ("B", C.c_void_p), ("C", C.c_void_p),
+        ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
+        ("lda", C.c_int32), ("ldb", C.c_int32), ("ldc", C.c_int32),
+        ("amap", RowMap), ("cmap", RowMap),
+        ("epi", C.c_uint32),
+        ("bias", C.c_void_p), ("resid", C.c_void_p), ("ldr", C.c_int32), ("rmap", RowMap),
+        ("rowscale", C.c_void_p), ("rows_per_sample", C.c_int32),
+        ("preact", C.c_void_p), ("ldp", C.c_int32),
+        ("tap", C.c_void_p), ("ldt", C.c_int32),
+    ]
+
+
+_lib = None
+_lock = threading.Lock()
+
+_SIGS = {
+    "dkd_version": (C.c_int, []),
+    "dkd_last_error": (C.c_char_p, []),
+    "dkd_device_info": (C.c_int, [C.c_int, C.POINTER(C.c_int), C.c_char_p, C.c_int]),
+    "dkd_gemm_nt": (C.c_int, [C.POINTER(Gemm), C.c_void_p]),
+    "dkd_gemm_tn": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                              C.c_int32, RowMap, RowMap, C.c_void_p]),
+    "dkd_attn_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "dkd_attn_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
+                               C.c_void_p]),
+    "dkd_layernorm_fwd": (C.c_int, [C.c_void_p, C.c_int32, RowMap, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                    C.c_int32, C.c_int32, C.c_float, C.c_int32, C.c_void_p]),
+    "dkd_layernorm_bwd": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, RowMap, C.c_void_p, C.c_void_p, C.c_void_p,
+                                    C.c_void_p, C.c_int32, RowMap, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
+                                    C.c_void_p]),
+    "dkd_im2col_patches": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "dkd_prefix_tokens_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "dkd_embed_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "dkd_scale_cast_bf16": (C.c_int, [C.c_void_p, C.c_int32, RowMap, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p,
+                                      C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "dkd_cast_weight": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
+    "dkd_colsum": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, RowMap, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
+    "dkd_add_rows": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, RowMap, C.c_int32, C.c_int32, C.c_int32,
+                               C.c_void_p]),
+    "dkd_logit_loss": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int32, C.c_void_p, C.c_void_p, C.c_float,
+                                 C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
+    "dkd_mse_loss": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, RowMap, C.c_void_p, C.c_float,
+                               C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "dkd_mask_select": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
+    "dkd_mask_select_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
+    "dkd_sort_l1_loss": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, RowMap, C.c_float, C.c_void_p,
+                                   C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "dkd_adamw_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float,
+                                 C.c_float, C.c_float, C.c_float, C.c_int32, C.c_float, C.c_void_p]),
+}
+EXPORTS = tuple(_SIGS)
+
+
+def lib():
+    """Load libdkd.so (once).  Raises RuntimeError when it has not been built: there is no fallback path."""
+    global _lib
+    if _lib is None:
+        with _lock:
+            if _lib is None:
+                if not os.path.exists(LIB_PATH):
+                    raise RuntimeError(
+                        f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                        "(hipcc --offload-arch=gfx950).  deltakd_amd has no CPU/eager fallback.")
+                handle = C.CDLL(LIB_PATH)
+                for name, (res, args) in _SIGS.items():
+                    fn = getattr(handle, name)
+                    fn.restype, fn.argtypes = res, args
+                _lib = handle
+    return _lib
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = lib().dkd_last_error().decode()
+        if rc == -1:
+            raise ValueError(f"libdkd {what}: {msg}")
+        raise RuntimeError(f"libdkd {what} failed ({rc}): {msg}")
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL).  Refuses host tensors: the kernels dereference device memory."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("deltakd_amd ops need tensors on an MI355X (cuda) device; there is no CPU path")
+    return t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream

@@ -1,0 +1,223 @@
+"""Tensor-level wrappers over the C ABI (one Python function per ``dkd_*`` entry point).
+
+No arithmetic happens here: the functions only check shapes/dtypes, pass raw device pointers + sizes to libdkd.so on
+torch's current HIP stream, and return the output tensors they allocated.
+"""
+import ctypes as C
+
+import torch
+
+from . import ffi
+from .ffi import (EPI_ACCUM, EPI_BIAS, EPI_DGELU, EPI_GELU, EPI_OUT_F32, EPI_RELU, EPI_RESID, EPI_TAP_F32, IDENT, RowMap,
+                  check, lib, ptr, stream)
+
+BF16, F32 = torch.bfloat16, torch.float32
+
+
+def _is_f32(t):
+    if t.dtype == F32:
+        return 1
+    if t.dtype == BF16:
+        return 0
+    raise TypeError(f"expected bf16 or f32 tensor, got {t.dtype}")
+
+
+def gemm_nt(a, b, out=None, *, M=None, bias=None, gelu=False, dgelu=False, relu=False, preact=None, resid=None, rowscale=None,
+            rows_per_sample=0, tap=None, out_f32=False, accumulate=False, amap=IDENT, cmap=IDENT, rmap=IDENT, out_rows=None,
+            K=None, N=None):
+    """out[M, N] = epilogue(a[M, K] @ b[N, K]^T); a, b bf16 (2-D, row stride = stride(0)).
+
+    ``M`` = logical rows (defaults to a.shape[0]; with ``amap`` the rows are gathered through the map).
+    ``out_rows`` = rows of the allocated output when ``cmap`` scatters into a larger buffer.
+    """
+    assert a.dtype == BF16 and b.dtype == BF16 and a.dim() == 2 and b.dim() == 2
+    assert a.stride(1) == 1 and b.stride(1) == 1
+    M = a.shape[0] if M is None else M
+    K = a.shape[1] if K is None else K
+    N = b.shape[0] if N is None else N
+    if out is None:
+        out = torch.empty(out_rows or M, N, device=a.device, dtype=F32 if out_f32 else BF16)
+    else:
+        out_f32 = out.dtype == F32
+    g = ffi.Gemm()
+    g.A, g.B, g.C = ptr(a), ptr(b), ptr(out)
+    g.M, g.N, g.K = M, N, K
+    g.lda, g.ldb, g.ldc = a.stride(0), b.stride(0), out.stride(0)
+    g.amap, g.cmap, g.rmap = amap, cmap, rmap
+    epi = 0
+    if bias is not None:
+        assert bias.dtype == F32 and bias.numel() >= N
+        epi |= EPI_BIAS
+        g.bias = ptr(bias)
+    if gelu:
+        epi |= EPI_GELU
+    if dgelu:
+        epi |= EPI_DGELU
+    if relu:
+        epi |= EPI_RELU
+    if preact is not None:
+        assert preact.dtype == BF16
+        g.preact, g.ldp = ptr(preact), preact.stride(0)
+    if resid is not None:
+        assert resid.dtype == F32
+        epi |= EPI_RESID
+        g.resid, g.ldr = ptr(resid), resid.stride(0)
+    if rowscale is not None:
+        assert rowscale.dtype == F32
+        g.rowscale, g.rows_per_sample = ptr(rowscale), rows_per_sample
+    if tap is not None:
+        g.tap, g.ldt = ptr(tap), tap.stride(0)
+        if tap.dtype == F32:
+            epi |= EPI_TAP_F32
+    if out_f32:
+        epi |= EPI_OUT_F32
+    if accumulate:
+        epi |= EPI_ACCUM
+    g.epi = epi
+    check(lib().dkd_gemm_nt(C.byref(g), stream()), "gemm_nt")
+    return out
+
+
+def gemm_tn(a, b, out, *, M=None, N1=None, N2=None, amap=IDENT, bmap=IDENT):
+    """out[N1, N2] (f32) += a[M, N1]^T @ b[M, N2]   (a, b bf16; rows through amap / bmap)."""
+    assert a.dtype == BF16 and b.dtype == BF16 and out.dtype == F32
+    M = a.shape[0] if M is None else M
+    N1 = a.shape[1] if N1 is None else N1
+    N2 = b.shape[1] if N2 is None else N2
+    check(lib().dkd_gemm_tn(ptr(a), ptr(b), ptr(out), M, N1, N2, a.stride(0), b.stride(0), out.stride(0), amap, bmap, stream()),
+          "gemm_tn")
+    return out
+
+
+def attn_fwd(qkv, B, N, H, need_lse=True):
+    """qkv bf16 [B*N, 3*H*64] -> (out bf16 [B*N, H*64], lse f32 [B, H, N] | None)."""
+    assert qkv.dtype == BF16 and qkv.is_contiguous() and qkv.numel() == B * N * 3 * H * 64
+    out = torch.empty(B * N, H * 64, device=qkv.device, dtype=BF16)
+    lse = torch.empty(B, H, N, device=qkv.device, dtype=F32) if need_lse else None
+    check(lib().dkd_attn_fwd(ptr(qkv), ptr(out), ptr(lse), B, N, H, stream()), "attn_fwd")
+    return out, lse
+
+
+def attn_bwd(qkv, out, dout, lse, B, N, H):
+    assert dout.dtype == BF16 and dout.is_contiguous() and out.is_contiguous() and qkv.is_contiguous()
+    dqkv = torch.empty_like(qkv)
+    check(lib().dkd_attn_bwd(ptr(qkv), ptr(out), ptr(dout), ptr(lse), ptr(dqkv), B, N, H, stream()), "attn_bwd")
+    return dqkv
+
+
+def layernorm_fwd(x, gamma, beta, *, M=None, xmap=IDENT, eps=1e-6, save_stats=True, out_f32=False):
+    """x f32 [rows, D] -> y bf16 [M, D] (+ mean, rstd f32 [M])."""
+    assert x.dtype == F32 and x.dim() == 2 and x.stride(1) == 1
+    M = x.shape[0] if M is None else M
+    D = x.shape[1]
+    y = torch.empty(M, D, device=x.device, dtype=F32 if out_f32 else BF16)
+    mean = torch.empty(M, device=x.device, dtype=F32) if save_stats else None
+    rstd = torch.empty(M, device=x.device, dtype=F32) if save_stats else None
+    check(lib().dkd_layernorm_fwd(ptr(x), x.stride(0), xmap, ptr(gamma), ptr(beta), ptr(y), ptr(mean), ptr(rstd), M, D, eps,
+                                  int(out_f32), stream()), "layernorm_fwd")
+    return y, mean, rstd
+
+
+def layernorm_bwd(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, *, M=None, xmap=IDENT, dxmap=IDENT, accumulate=False):
+    """dx (f32, in place) (+)= LN'(dy); dgamma/dbeta (f32 [D]) += ."""
+    M = dy.shape[0] if M is None else M
+    D = x.shape[1]
+    assert dy.is_contiguous() and dy.shape[1] == D
+    check(lib().dkd_layernorm_bwd(ptr(dy), _is_f32(dy), ptr(x), x.stride(0), xmap, ptr(gamma), ptr(mean), ptr(rstd), ptr(dx),
+                                  dx.stride(0), dxmap, int(accumulate), ptr(dgamma), ptr(dbeta), M, D, stream()), "layernorm_bwd")
+    return dx
+
+
+def im2col_patches(img, p):
+    assert img.dtype == F32 and img.is_contiguous() and img.dim() == 4
+    B, Cc, H, W = img.shape
+    out = torch.empty(B * (H // p) * (W // p), Cc * p * p, device=img.device, dtype=BF16)
+    check(lib().dkd_im2col_patches(ptr(img), ptr(out), B, Cc, H, W, p, stream()), "im2col")
+    return out
+
+
+def prefix_tokens_fwd(x, tok, pos, B, N, D, npre):
+    check(lib().dkd_prefix_tokens_fwd(ptr(x), ptr(tok), ptr(pos), B, N, D, npre, stream()), "prefix_tokens")
+
+
+def embed_bwd(dx, dtok, dpos, B, N, D, npre):
+    check(lib().dkd_embed_bwd(ptr(dx), ptr(dtok), ptr(dpos), B, N, D, npre, stream()), "embed_bwd")
+
+
+def scale_cast_bf16(x, *, M=None, xmap=IDENT, rowscale=None, rows_per_sample=0, add=None, ld_out=None):
+    assert x.dtype == F32 and x.dim() == 2
+    M = x.shape[0] if M is None else M
+    D = x.shape[1]
+    ld = ld_out or D
+    y = torch.empty(M, ld, device=x.device, dtype=BF16) if ld == D else torch.zeros(M, ld, device=x.device, dtype=BF16)
+    check(lib().dkd_scale_cast_bf16(ptr(x), x.stride(0), xmap, ptr(rowscale), rows_per_sample, ptr(add),
+                                    add.stride(0) if add is not None else 0, ptr(y), ld, M, D, stream()), "scale_cast")
+    return y
+
+
+def cast_weight(w, w_bf16=None, w_t_bf16=None):
+    """w f32 [rows, cols] (contiguous) -> bf16 copy and/or bf16 transpose, written into the given buffers."""
+    assert w.dtype == F32 and w.is_contiguous()
+    rows = w.shape[0]
+    cols = w.numel() // rows
+    check(lib().dkd_cast_weight(ptr(w), ptr(w_bf16), ptr(w_t_bf16), rows, cols, stream()), "cast_weight")
+
+
+def colsum(x, out, *, M=None, N=None, xmap=IDENT):
+    M = x.shape[0] if M is None else M
+    N = x.shape[1] if N is None else N
+    check(lib().dkd_colsum(ptr(x), _is_f32(x), x.stride(0), xmap, ptr(out), M, N, stream()), "colsum")
+    return out
+
+
+def add_rows(x, y, *, ymap=IDENT, accumulate=True, M=None):
+    M = x.shape[0] if M is None else M
+    check(lib().dkd_add_rows(ptr(x), _is_f32(x), x.stride(0), ptr(y), y.stride(0), ymap, M, x.shape[1], int(accumulate), stream()),
+          "add_rows")
+    return y
+
+
+def logit_loss(z, target, *, smoothing=0.1, kd_mode=0, z_kd=None, z_t=None, tau=1.0, w_base=1.0, w_kd=0.0):
+    """-> (losses f32 [2] = (base, distill), dz, dz_kd | None).  target: f32 [B, C] soft targets or int64 [B] labels."""
+    assert z.dtype == F32 and z.is_contiguous()
+    B, Cc = z.shape
+    soft = target if target.dtype == F32 else None
+    labels = target if target.dtype == torch.int64 else None
+    if soft is None and labels is None:
+        raise TypeError("target must be f32 soft targets or int64 labels")
+    losses = torch.zeros(2, device=z.device, dtype=F32)
+    dz = torch.empty_like(z)
+    dz_kd = torch.empty_like(z) if kd_mode else None
+    if kd_mode:
+        assert z_kd.is_contiguous() and z_t.is_contiguous() and z_kd.dtype == F32 and z_t.dtype == F32
+    check(lib().dkd_logit_loss(ptr(z), ptr(soft), ptr(labels), smoothing, kd_mode, ptr(z_kd), ptr(z_t), tau, w_base, w_kd,
+                               ptr(losses), ptr(dz), ptr(dz_kd), B, Cc, stream()), "logit_loss")
+    return losses, dz, dz_kd
+
+
+def mse_loss(a, t, loss, w_over_denom, *, M=None, tmap=IDENT, mask=None, grad=True, grad_f32=False):
+    """loss[0] += w/denom * sum(mask (a - t)^2); returns d loss / d a (same shape as a) or None."""
+    M = a.shape[0] if M is None else M
+    D = a.shape[1]
+    da = torch.empty(M, D, device=a.device, dtype=F32 if grad_f32 else BF16) if grad else None
+    check(lib().dkd_mse_loss(ptr(a), _is_f32(a), a.stride(0), ptr(t), _is_f32(t), t.stride(0), tmap, ptr(mask), w_over_denom,
+                             ptr(loss), ptr(da), int(grad_f32), D, M, D, stream()), "mse_loss")
+    return da
+
+
+def mask_select(x, mask_token, mask):
+    out = torch.empty_like(x)
+    check(lib().dkd_mask_select(ptr(x), ptr(mask_token), ptr(mask), ptr(out), x.shape[0], x.shape[1], stream()), "mask_select")
+    return out
+
+
+def mask_select_bwd(dout, mask, dmask_token):
+    dx = torch.empty_like(dout)
+    check(lib().dkd_mask_select_bwd(ptr(dout), ptr(mask), ptr(dx), ptr(dmask_token), dout.shape[0], dout.shape[1], stream()),
+          "mask_select_bwd")
+    return dx
+
+
+def adamw_step(p, g, m, v, p_bf16, lr, beta1, beta2, eps, wd, step, grad_scale=1.0):
+    check(lib().dkd_adamw_step(ptr(p), ptr(g), ptr(m), ptr(v), ptr(p_bf16), p.numel(), lr, beta1, beta2, eps, wd, step, grad_scale,
+                               stream()), "adamw")

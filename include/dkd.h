@@ -1,0 +1,148 @@
+/*
+ * dkd.h -- C ABI of libdkd.so: hand-written gfx950 (MI355X / CDNA4) HIP kernels for the
+ * DeiT teacher->student distillation training step.
+ *
+ * The reference (serizard/DeltaKD) has no native code and no FFI: every op below replaces the
+ * ATen/cuBLAS/cuDNN kernel that the cited reference line causes through timm==0.9.12 / torch.
+ * (file:line are relative to /root/reference; [3P] = inside timm, reached from that call site.)
+ *
+ * Conventions
+ *   - plain pointers + sizes; every pointer is DEVICE memory owned by the caller (torch tensors on the
+ *     Python side); the library never allocates, frees or retains caller memory after return.
+ *   - all launches are asynchronous on `stream` (a hipStream_t passed as void*; NULL = default stream).
+ *   - return 0 on success, <0 on error; dkd_last_error() returns a thread-local message.
+ *   - bf16 tensors are raw uint16_t payloads; "f32" = float.
+ *   - no global mutable state: safe to call from torch's main and autograd threads concurrently.
+ */
+#ifndef DKD_H
+#define DKD_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DKD_OK 0
+#define DKD_ERR_ARG (-1)
+#define DKD_ERR_HIP (-2)
+#define DKD_ERR_UNSUPPORTED (-3)
+
+int dkd_version(void);
+const char* dkd_last_error(void);
+/* number of compute units / name of device 0 as seen by HIP (diagnostics for bench.py) */
+int dkd_device_info(int device, int* cu_count, char* name, int name_len);
+
+/* Row map: physical_row(m) = rpg > 0 ? (m / rpg) * gstride + (m % rpg) + off : m.
+ * Expresses "all patch tokens of every sample, prefix tokens stripped" (feat[:, npre:], model/loss.py:88-98)
+ * and "broadcast over the batch" (gstride = 0: pos_embed) without materialising a copy. */
+typedef struct { int32_t rpg, gstride, off; } DkdRowMap;
+
+/* ---------------------------------------------------------------- GEMM (bf16 MFMA, fp32 accumulate) */
+enum {
+  DKD_EPI_BIAS        = 1 << 0,  /* v += bias[n]                                             */
+  DKD_EPI_GELU        = 1 << 1,  /* v = gelu_erf(v); if preact != NULL the pre-activation is stored (bf16) */
+  DKD_EPI_DGELU       = 1 << 2,  /* v *= gelu'(preact[m,n])   (backward of fc1's GELU)        */
+  DKD_EPI_RESID       = 1 << 3,  /* v = resid[rmap(m), n] + rowscale[m / rows_per_sample] * v */
+  DKD_EPI_OUT_F32     = 1 << 4,  /* C is float (default: bf16)                               */
+  DKD_EPI_TAP_F32     = 1 << 5,  /* tap (value before RESID) stored as float (default bf16)   */
+  DKD_EPI_RELU        = 1 << 6,  /* v = max(v, 0)                                            */
+  DKD_EPI_ACCUM       = 1 << 7   /* C += v (f32 output only)                                  */
+};
+
+typedef struct {
+  const void* A;      /* bf16 [M, K], row stride lda (elements), rows through amap            */
+  const void* B;      /* bf16 [N, K], row stride ldb : C = A * B^T  (torch Linear weight layout) */
+  void* C;            /* bf16 or f32 [M, N], row stride ldc, rows through cmap                */
+  int32_t M, N, K;
+  int32_t lda, ldb, ldc;
+  DkdRowMap amap, cmap;
+  uint32_t epi;       /* DKD_EPI_* flags                                                      */
+  const float* bias;  /* f32 [N]                                                              */
+  const float* resid; /* f32, row stride ldr, rows through rmap                               */
+  int32_t ldr;
+  DkdRowMap rmap;
+  const float* rowscale; /* f32 [M / rows_per_sample] (DropPath keep/keep_prob) or NULL (=1)    */
+  int32_t rows_per_sample;
+  void* preact;       /* bf16 [M, N] row stride ldp: written by GELU, read by DGELU           */
+  int32_t ldp;
+  void* tap;          /* optional copy of (acc + bias) before RESID (the feature tap of
+                         model/models.py:189-191), row stride ldt, rows = m                   */
+  int32_t ldt;
+} DkdGemm;
+
+/* C[M,N] = epilogue(A[M,K] * B[N,K]^T).  Replaces nn.Linear / Conv2d-as-GEMM forward and the dgrad GEMMs
+ * ([3P] timm Attention/Mlp/PatchEmbed reached from model/models.py:195; align layers model/loss.py:89-91,426).
+ * Requires K % 64 == 0 and 16-byte aligned rows. */
+int dkd_gemm_nt(const DkdGemm* g, void* stream);
+
+/* C[N1,N2] += sum_m A[m,N1] * B[m,N2]   (weight gradients; f32 atomics into C, row stride ldc).
+ * A, B bf16 with row strides lda/ldb and row maps; M is the reduction length. */
+int dkd_gemm_tn(const void* A, const void* B, float* C, int32_t M, int32_t N1, int32_t N2, int32_t lda, int32_t ldb,
+                int32_t ldc, DkdRowMap amap, DkdRowMap bmap, void* stream);
+
+/* ---------------------------------------------------------------- attention ([3P] F.scaled_dot_product_attention) */
+/* qkv bf16 [B, N, 3, H, 64] (the fused qkv Linear output, no head-split copy); out bf16 [B, N, H*64];
+ * lse f32 [B, H, N] (natural-log sum-exp of the scaled scores, saved for backward; may be NULL). N <= 256. */
+int dkd_attn_fwd(const void* qkv, void* out, float* lse, int32_t B, int32_t N, int32_t H, void* stream);
+/* dqkv bf16 [B, N, 3, H, 64] from dout bf16 [B, N, H*64]. */
+int dkd_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, int32_t B, int32_t N,
+                 int32_t H, void* stream);
+
+/* ---------------------------------------------------------------- LayerNorm ([3P] nn.LayerNorm eps 1e-6) */
+/* x f32 [M, D] (rows through xmap) -> y bf16 [M, D] contiguous rows; mean/rstd f32 [M] saved when non-NULL. */
+int dkd_layernorm_fwd(const float* x, int32_t ldx, DkdRowMap xmap, const float* gamma, const float* beta, void* y,
+                      float* mean, float* rstd, int32_t M, int32_t D, float eps, int32_t y_is_f32, void* stream);
+/* dx f32 [M, D] = (accumulate ? dx : 0) + LN'(dy); dgamma/dbeta f32 [D] += (atomics).  dy bf16 or f32 [M, D]. */
+int dkd_layernorm_bwd(const void* dy, int32_t dy_is_f32, const float* x, int32_t ldx, DkdRowMap xmap, const float* gamma,
+                      const float* mean, const float* rstd, float* dx, int32_t lddx, DkdRowMap dxmap, int32_t accumulate,
+                      float* dgamma, float* dbeta, int32_t M, int32_t D, void* stream);
+
+/* ---------------------------------------------------------------- data movement / elementwise */
+/* img f32 [B, C, H, W] -> patches bf16 [B*(H/p)*(W/p), C*p*p] in Conv2d weight order (c, i, j). ([3P] PatchEmbed) */
+int dkd_im2col_patches(const float* img, void* patches, int32_t B, int32_t C, int32_t H, int32_t W, int32_t p, void* stream);
+/* x[b, t, :] = tok[t, :] + pos[t, :] for the npre prefix tokens (cls[, dist]); x f32 [B, N, D]. */
+int dkd_prefix_tokens_fwd(float* x, const float* tok, const float* pos, int32_t B, int32_t N, int32_t D, int32_t npre, void* stream);
+/* dtok[t,:] += sum_b dx[b,t,:] (t < npre);  dpos[t,:] += sum_b dx[b,t,:] (all t). */
+int dkd_embed_bwd(const float* dx, float* dtok, float* dpos, int32_t B, int32_t N, int32_t D, int32_t npre, void* stream);
+/* y bf16 [M, D] = (rowscale ? rowscale[m / rows_per_sample] : 1) * x[xmap(m)] (+ add[m] if add) ; x, add f32. */
+int dkd_scale_cast_bf16(const float* x, int32_t ldx, DkdRowMap xmap, const float* rowscale, int32_t rows_per_sample,
+                        const float* add, int32_t ldadd, void* y, int32_t ldy, int32_t M, int32_t D, void* stream);
+/* f32 -> bf16 flat cast; optionally also the transpose of a [rows, cols] matrix (w_t may be NULL). */
+int dkd_cast_weight(const float* w, void* w_bf16, void* w_t_bf16, int32_t rows, int32_t cols, void* stream);
+/* out[n] += sum_m x[amap(m), n]; x bf16 (or f32 if x_is_f32) [M, N] : bias gradients. */
+int dkd_colsum(const void* x, int32_t x_is_f32, int32_t ldx, DkdRowMap xmap, float* out, int32_t M, int32_t N, void* stream);
+/* y f32 [M, D] (+)= x (bf16 or f32) scattered through ymap rows (gradient of a token-strip view). */
+int dkd_add_rows(const void* x, int32_t x_is_f32, int32_t ldx, float* y, int32_t ldy, DkdRowMap ymap, int32_t M, int32_t D,
+                 int32_t accumulate, void* stream);
+
+/* ---------------------------------------------------------------- losses (fused value + gradient) */
+/* Base criterion + optional logit distillation in one pass (model/loss.py:35,57-67,241; timm SoftTargetCrossEntropy /
+ * LabelSmoothingCrossEntropy [3P]).  z f32 [B, C] student logits; exactly one of soft_target f32 [B, C] / labels i64 [B].
+ * kd_mode 0 none, 1 soft (KL, tau, /(B*C)), 2 hard (CE vs argmax teacher); z_kd/z_t f32 [B, C].
+ * Outputs: losses[0] = base, losses[1] = distill (sums accumulated atomically: caller zeroes losses first),
+ * dz = w_base * dbase/dz, dz_kd = w_kd * ddistill/dz_kd   (f32 [B, C]). */
+int dkd_logit_loss(const float* z, const float* soft_target, const int64_t* labels, float smoothing, int32_t kd_mode,
+                   const float* z_kd, const float* z_t, float tau, float w_base, float w_kd, float* losses, float* dz,
+                   float* dz_kd, int32_t B, int32_t C, void* stream);
+/* loss[0] += w * sum(mask * (a - t)^2) / denom ; da = 2 w mask (a - t) / denom.  a: bf16|f32 [M, D] (student side, gets
+ * the gradient), t: bf16|f32 [M, D] rows through tmap; mask f32 [M] or NULL.  (model/loss.py:326,449-451) */
+int dkd_mse_loss(const void* a, int32_t a_is_f32, int32_t lda, const void* t, int32_t t_is_f32, int32_t ldt, DkdRowMap tmap,
+                 const float* mask, float w_over_denom, float* loss, void* da, int32_t da_is_f32, int32_t ldda, int32_t M,
+                 int32_t D, void* stream);
+/* x~ = mask ? mask_token : x   (model/loss.py:433-440 collapsed); x, out bf16 [M, D], mask f32 [M]. */
+int dkd_mask_select(const void* x, const float* mask_token, const float* mask, void* out, int32_t M, int32_t D, void* stream);
+/* backward of mask_select: dx = (1-mask) * dout (bf16), dmask_token[d] += sum_{masked m} dout[m, d]. */
+int dkd_mask_select_bwd(const void* dout, const float* mask, void* dx, float* dmask_token, int32_t M, int32_t D, void* stream);
+/* WassKD-L1 (model/loss.py:187-199): per (b, d) sort over the P tokens of s (bf16|f32 [B, P, D]) and t ([B, P, D] rows
+ * through tmap); loss[0] += w * sum|sort(s) - sort(t)| ; ds[b, pi(j), d] = w * sign(delta_j).  P <= 256. */
+int dkd_sort_l1_loss(const void* s, int32_t s_is_f32, const void* t, int32_t t_is_f32, int32_t ldt, DkdRowMap tmap, float w,
+                     float* loss, void* ds, int32_t ds_is_f32, int32_t B, int32_t P, int32_t D, void* stream);
+
+/* ---------------------------------------------------------------- optimizer ([3P] torch.optim.AdamW via timm create_optimizer) */
+/* One launch over a flat parameter segment; optionally refreshes the bf16 shadow copy used by the GEMMs. */
+int dkd_adamw_step(float* p, const float* g, float* m, float* v, void* p_bf16, int64_t n, float lr, float beta1, float beta2,
+                   float eps, float weight_decay, int32_t step, float grad_scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

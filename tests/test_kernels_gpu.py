@@ -1,0 +1,296 @@
+"""Per-kernel parity: every dkd_* entry point, called through the C ABI, against plain torch fp32 on the same inputs
+(bf16 operands are rounded once; the reference then computes in fp32).  Tolerances are stated per test."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+BF16, F32 = torch.bfloat16, torch.float32
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from deltakd_amd import ops as o
+    o.lib()
+    return o
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def rnd(*shape, scale=1.0, seed=0):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(dev())
+
+
+def close(got, ref, rel, what=""):
+    got, ref = got.float(), ref.float()
+    err = (got - ref).abs().max().item()
+    scale = ref.abs().max().item() + 1e-12
+    assert math.isfinite(err) and err <= rel * scale, f"{what}: max abs err {err:.4e} vs scale {scale:.4e} (rel {err/scale:.3e} > {rel})"
+
+
+# bf16 output rounding is 2^-9 relative; fp32 accumulation over K<=3072 of bf16 products adds ~1e-6: 1e-2 of the
+# output scale is a loose-enough bound that still catches any indexing error.
+@pytest.mark.parametrize("M,N,K", [(256, 128, 64), (300, 192, 192), (1000, 576, 192), (129, 1000, 192), (513, 64, 768),
+                                   (130, 16, 64), (4 * 197, 768, 3072), (64, 10, 64)])
+def test_gemm_nt_plain(ops, M, N, K):
+    a = rnd(M, K, seed=1).to(BF16)
+    b = rnd(N, K, seed=2).to(BF16)
+    ref = a.float() @ b.float().t()
+    close(ops.gemm_nt(a, b), ref, 1e-2, "bf16 out")
+    close(ops.gemm_nt(a, b, out_f32=True), ref, 2e-5 * math.sqrt(K), "f32 out")
+
+
+def test_gemm_nt_epilogues(ops):
+    from deltakd_amd.ffi import RowMap, strip_map
+    B, Nt, D, Hd = 6, 17, 128, 256
+    M = B * Nt
+    x = rnd(M, D, seed=3).to(BF16)
+    w = rnd(Hd, D, scale=0.1, seed=4).to(BF16)
+    bias = rnd(Hd, seed=5)
+    pre = torch.empty(M, Hd, device=dev(), dtype=BF16)
+    h = ops.gemm_nt(x, w, bias=bias, gelu=True, preact=pre)
+    ref_pre = x.float() @ w.float().t() + bias
+    close(pre, ref_pre, 1e-2, "preact")
+    close(h, torch.nn.functional.gelu(ref_pre), 1e-2, "gelu")
+    # dgelu epilogue
+    dy = rnd(M, D, seed=6).to(BF16)
+    wt = w.t().contiguous()          # [D, Hd] -> B operand [N=Hd, K=D] is w itself: dH = dy @ w^T ... use w as B
+    dh = ops.gemm_nt(dy, w, dgelu=True, preact=pre)
+    xg = pre.float().requires_grad_(True)
+    torch.nn.functional.gelu(xg).backward(dy.float() @ w.float().t())
+    close(dh, xg.grad, 1e-2, "dgelu")
+    # residual + rowscale + tap, f32 out
+    w2 = rnd(D, Hd, scale=0.1, seed=7).to(BF16)
+    b2 = rnd(D, seed=8)
+    resid = rnd(M, D, seed=9)
+    scale = torch.tensor([1.0, 0.0, 1.25, 1.0, 0.0, 1.1], device=dev())
+    tap = torch.empty(M, D, device=dev(), dtype=BF16)
+    out = ops.gemm_nt(h, w2, bias=b2, resid=resid, rowscale=scale, rows_per_sample=Nt, tap=tap, out_f32=True)
+    f = h.float() @ w2.float().t() + b2
+    close(tap, f, 1e-2, "tap")
+    ref = resid + scale.repeat_interleave(Nt)[:, None] * f
+    close(out, ref, 1e-2, "resid")
+    # A rows through a strip map (drop 1 prefix token per sample), C rows scattered back through a map
+    P = Nt - 1
+    s = ops.gemm_nt(x, w, M=B * P, amap=strip_map(Nt, 1), out_f32=True)
+    xs = x.view(B, Nt, D)[:, 1:].reshape(B * P, D)
+    close(s, xs.float() @ w.float().t(), 1e-2, "amap")
+    big = torch.zeros(M, Hd, device=dev(), dtype=BF16)
+    ops.gemm_nt(xs.contiguous(), w, out=big, cmap=strip_map(Nt, 1))
+    exp = torch.zeros(B, Nt, Hd, device=dev())
+    exp[:, 1:] = (xs.float() @ w.float().t()).view(B, P, Hd)
+    close(big, exp.view(M, Hd), 1e-2, "cmap")
+    # broadcast residual (pos_embed) through rmap with gstride 0, relu, accumulate
+    pos = rnd(Nt, Hd, seed=10)
+    o2 = ops.gemm_nt(xs.contiguous(), w, out=torch.zeros(M, Hd, device=dev()), cmap=strip_map(Nt, 1), resid=pos,
+                     rmap=RowMap(P, 0, 1))
+    exp2 = torch.zeros(B, Nt, Hd, device=dev())
+    exp2[:, 1:] = (xs.float() @ w.float().t()).view(B, P, Hd) + pos[1:]
+    close(o2, exp2.view(M, Hd), 1e-2, "pos resid")
+    acc = torch.ones(M, Hd, device=dev())
+    ops.gemm_nt(x, w, out=acc, relu=True, accumulate=True)
+    close(acc, 1 + torch.relu(x.float() @ w.float().t()), 1e-2, "relu+accum")
+
+
+@pytest.mark.parametrize("M,N1,N2", [(64, 128, 128), (1000, 192, 576), (4 * 196, 768, 192), (777, 16, 64), (300, 10, 64),
+                                     (5000, 256, 384)])
+def test_gemm_tn(ops, M, N1, N2):
+    ld1, ld2 = (N1 + 7) // 8 * 8, (N2 + 7) // 8 * 8
+    a = torch.zeros(M, ld1, device=dev(), dtype=BF16)
+    b = torch.zeros(M, ld2, device=dev(), dtype=BF16)
+    a[:, :N1] = rnd(M, N1, seed=11).to(BF16)
+    b[:, :N2] = rnd(M, N2, seed=12).to(BF16)
+    out = torch.full((N1, N2), 0.5, device=dev())
+    ops.gemm_tn(a, b, out, N1=N1, N2=N2)
+    ref = 0.5 + a[:, :N1].float().t() @ b[:, :N2].float()
+    close(out, ref, 3e-5 * math.sqrt(M), "tn")
+
+
+def test_gemm_tn_rowmaps(ops):
+    from deltakd_amd.ffi import strip_map
+    B, Nt, D1, D2 = 5, 18, 64, 128
+    a = rnd(B * Nt, D1, seed=13).to(BF16)
+    b = rnd(B * (Nt - 2), D2, seed=14).to(BF16)
+    out = torch.zeros(D1, D2, device=dev())
+    ops.gemm_tn(a, b, out, M=B * (Nt - 2), amap=strip_map(Nt, 2))
+    ref = a.view(B, Nt, D1)[:, 2:].reshape(-1, D1).float().t() @ b.float()
+    close(out, ref, 1e-4, "tn amap")
+
+
+def ref_attention(qkv, B, N, H):
+    q, k, v = qkv.float().view(B, N, 3, H, 64).permute(2, 0, 3, 1, 4)
+    s = (q @ k.transpose(-1, -2)) * 0.125
+    p = s.softmax(-1)
+    return (p @ v).transpose(1, 2).reshape(B * N, H * 64), torch.logsumexp(s, -1)
+
+
+@pytest.mark.parametrize("B,N,H", [(2, 17, 1), (3, 18, 2), (2, 197, 3), (2, 198, 12), (1, 64, 2), (1, 256, 1), (2, 100, 2)])
+def test_attn_fwd_bwd(ops, B, N, H):
+    qkv = rnd(B * N, 3 * H * 64, scale=1.5, seed=20).to(BF16)
+    out, lse = ops.attn_fwd(qkv, B, N, H)
+    ref, ref_lse = ref_attention(qkv, B, N, H)
+    close(out, ref, 1.5e-2, "attn out")     # P is rounded to bf16 before PV: 2^-9 relative per term
+    close(lse, ref_lse, 1e-3, "lse")
+    dout = rnd(B * N, H * 64, seed=21).to(BF16)
+    x = qkv.float().requires_grad_(True)
+    r, _ = ref_attention(x, B, N, H)
+    r.backward(dout.float())
+    dqkv = ops.attn_bwd(qkv, out, dout, lse, B, N, H)
+    g = x.grad.view(B, N, 3, H, 64)
+    d = dqkv.float().view(B, N, 3, H, 64)
+    for i, nm in enumerate("qkv"):
+        close(d[:, :, i], g[:, :, i], 3e-2, f"d{nm}")
+
+
+@pytest.mark.parametrize("M,D", [(7, 64), (300, 192), (129, 768), (50, 1024)])
+def test_layernorm(ops, M, D):
+    x = rnd(M, D, scale=2.0, seed=30) + 0.5
+    gamma = 1 + 0.1 * rnd(D, seed=31)
+    beta = 0.1 * rnd(D, seed=32)
+    y, mean, rstd = ops.layernorm_fwd(x, gamma, beta)
+    xr = x.clone().requires_grad_(True)
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    ref = torch.nn.functional.layer_norm(xr, (D,), gr, br, 1e-6)
+    close(y, ref, 6e-3, "ln fwd (bf16 out)")
+    y32, _, _ = ops.layernorm_fwd(x, gamma, beta, out_f32=True)
+    close(y32, ref, 1e-5, "ln fwd f32")
+    dy = rnd(M, D, seed=33).to(BF16)
+    ref.backward(dy.float())
+    dx = torch.ones(M, D, device=dev())
+    dg, db = torch.zeros(D, device=dev()), torch.zeros(D, device=dev())
+    ops.layernorm_bwd(dy, x, gamma, mean, rstd, dx, dg, db, accumulate=True)
+    close(dx - 1, xr.grad, 1e-4, "ln dx")
+    close(dg, gr.grad, 1e-4, "ln dgamma")
+    close(db, br.grad, 1e-4, "ln dbeta")
+
+
+def test_im2col_and_embed(ops):
+    B, C, H, p, D = 3, 3, 32, 8, 64
+    img = rnd(B, C, H, H, seed=40)
+    w = rnd(D, C, p, p, scale=0.1, seed=41)
+    bias = rnd(D, seed=42)
+    patches = ops.im2col_patches(img, p)
+    ref = torch.nn.functional.conv2d(img.to(BF16).float(), w.to(BF16).float(), bias, stride=p).flatten(2).transpose(1, 2)
+    got = ops.gemm_nt(patches, w.view(D, -1).to(BF16).contiguous(), bias=bias, out_f32=True)
+    close(got, ref.reshape(-1, D), 1e-4 * 14, "patch embed")
+    # prefix tokens + embed backward
+    N, npre = 18, 2
+    x = torch.zeros(B * N, D, device=dev())
+    tok, pos = rnd(npre, D, seed=43), rnd(N, D, seed=44)
+    ops.prefix_tokens_fwd(x, tok, pos, B, N, D, npre)
+    assert torch.equal(x.view(B, N, D)[:, :npre], (tok + pos[:npre]).expand(B, npre, D))
+    dx = rnd(B * N, D, seed=45)
+    dtok, dpos = torch.zeros(npre, D, device=dev()), torch.zeros(N, D, device=dev())
+    ops.embed_bwd(dx, dtok, dpos, B, N, D, npre)
+    close(dpos, dx.view(B, N, D).sum(0), 1e-5, "dpos")
+    close(dtok, dx.view(B, N, D)[:, :npre].sum(0), 1e-5, "dtok")
+
+
+def test_elementwise(ops):
+    from deltakd_amd.ffi import strip_map
+    B, N, D = 4, 17, 64
+    x = rnd(B * N, D, seed=50)
+    sc = torch.tensor([1.0, 0.0, 2.0, 1.5], device=dev())
+    add = rnd(B * N, D, seed=51)
+    y = ops.scale_cast_bf16(x, rowscale=sc, rows_per_sample=N, add=add)
+    assert torch.equal(y, (x * sc.repeat_interleave(N)[:, None] + add).to(BF16))
+    ys = ops.scale_cast_bf16(x, M=B * (N - 1), xmap=strip_map(N, 1))
+    assert torch.equal(ys, x.view(B, N, D)[:, 1:].reshape(-1, D).to(BF16))
+    w = rnd(100, 72, seed=52)
+    wb, wt = torch.empty(100, 72, device=dev(), dtype=BF16), torch.empty(72, 100, device=dev(), dtype=BF16)
+    ops.cast_weight(w, wb, wt)
+    assert torch.equal(wb, w.to(BF16)) and torch.equal(wt, w.to(BF16).t())
+    cs = torch.zeros(D, device=dev())
+    ops.colsum(y, cs)
+    close(cs, y.float().sum(0), 1e-5, "colsum")
+    tgt = torch.ones(B * N, D, device=dev())
+    ops.add_rows(ys, tgt, ymap=strip_map(N, 1))
+    exp = torch.ones(B, N, D, device=dev())
+    exp[:, 1:] += ys.float().view(B, N - 1, D)
+    close(tgt, exp.view(-1, D), 1e-6, "add_rows")
+
+
+@pytest.mark.parametrize("C", [10, 100, 1000])
+def test_logit_loss(ops, C):
+    import torch.nn.functional as F
+    B = 9
+    z, zk, zt = rnd(B, C, scale=2, seed=60), rnd(B, C, scale=2, seed=61), rnd(B, C, scale=3, seed=62)
+    y = torch.softmax(rnd(B, C, seed=63), 1)
+    lab = torch.randint(0, C, (B,), generator=torch.Generator().manual_seed(1)).to(dev())
+    for target in (y, lab):
+        for mode, wb, wk in ((0, 1.0, 0.0), (1, 0.9, 0.1), (2, 0.5, 0.5)):
+            zr, zkr = z.clone().requires_grad_(True), zk.clone().requires_grad_(True)
+            if target.dtype == F32:
+                base = torch.sum(-target * F.log_softmax(zr, -1), -1).mean()
+            else:
+                lp = F.log_softmax(zr, -1)
+                base = (0.9 * -lp.gather(1, target[:, None]).squeeze(1) + 0.1 * -lp.mean(-1)).mean()
+            if mode == 1:
+                T = 3.0
+                kd = F.kl_div(F.log_softmax(zkr / T, 1), F.log_softmax(zt / T, 1), reduction="sum", log_target=True) * T * T / zkr.numel()
+            elif mode == 2:
+                kd = F.cross_entropy(zkr, zt.argmax(1))
+            else:
+                kd = zkr.sum() * 0
+            (wb * base + wk * kd).backward()
+            losses, dz, dzk = ops.logit_loss(z, target, smoothing=0.1, kd_mode=mode, z_kd=zk, z_t=zt, tau=3.0, w_base=wb, w_kd=wk)
+            close(losses[0], base.detach(), 1e-5, "base")
+            close(dz, zr.grad, 1e-4, "dz")
+            if mode:
+                close(losses[1], kd.detach(), 1e-5, "kd")
+                close(dzk, zkr.grad, 1e-4, "dz_kd")
+
+
+def test_mse_and_mask(ops):
+    from deltakd_amd.ffi import strip_map
+    B, N, D = 3, 18, 64
+    P = N - 2
+    a = rnd(B * P, D, seed=70).to(BF16)
+    t = rnd(B * N, D, seed=71).to(BF16)
+    mask = (rnd(B * P, seed=72) > 0).float()
+    w = 7e-5 / (B * P * D)
+    loss = torch.zeros(1, device=dev())
+    da = ops.mse_loss(a, t, loss, w, tmap=strip_map(N, 2), mask=mask, grad_f32=True)
+    ar = a.float().requires_grad_(True)
+    tt = t.float().view(B, N, D)[:, 2:].reshape(-1, D)
+    ref = 7e-5 * torch.nn.functional.mse_loss(ar * mask[:, None], tt * mask[:, None])
+    ref.backward()
+    close(loss, ref.detach(), 1e-5, "mse")
+    close(da, ar.grad, 1e-5, "mse grad")
+    tok = rnd(D, seed=73)
+    xs = ops.mask_select(a, tok, mask)
+    exp = torch.where(mask[:, None] > 0, tok.to(BF16)[None], a)
+    assert torch.equal(xs, exp)
+    dout = rnd(B * P, D, seed=74).to(BF16)
+    dtok = torch.zeros(D, device=dev())
+    dx = ops.mask_select_bwd(dout, mask, dtok)
+    assert torch.equal(dx, torch.where(mask[:, None] > 0, torch.zeros_like(dout), dout))
+    close(dtok, (dout.float() * mask[:, None]).sum(0), 1e-5, "dtok")
+
+
+def test_adamw(ops):
+    n = 10007
+    p, g = rnd(n, seed=80), rnd(n, seed=81)
+    pr = p.clone().requires_grad_(True)
+    opt = torch.optim.AdamW([pr], lr=5e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.05)
+    m, v = torch.zeros(n, device=dev()), torch.zeros(n, device=dev())
+    pb = torch.empty(n, device=dev(), dtype=BF16)
+    for step in range(1, 4):
+        pr.grad = g.clone() * step
+        opt.step()
+        ops.adamw_step(p, g * step, m, v, pb, 5e-4, 0.9, 0.999, 1e-8, 0.05, step)
+    close(p, pr.detach(), 1e-6, "adamw")
+    assert torch.equal(pb, p.to(BF16))
+
+
+def test_errors_are_loud(ops):
+    a = torch.zeros(4, 60, device=dev(), dtype=BF16)
+    with pytest.raises(ValueError):
+        ops.gemm_nt(a, a)            # K not a multiple of 64
+    with pytest.raises(RuntimeError):
+        ops.gemm_nt(torch.zeros(4, 64, dtype=BF16), torch.zeros(4, 64, dtype=BF16))   # host tensors

@@ -42,14 +42,21 @@ __global__ void embed_bwd_kernel(const float* __restrict__ dx, float* __restrict
 }
 
 __global__ void scale_cast_kernel(const float* __restrict__ x, int ldx, DkdRowMap xmap, const float* __restrict__ rowscale, int rps,
-                                  const float* __restrict__ add, int ldadd, bf16_t* __restrict__ y, int ldy, int M, int D) {
+                                  const void* __restrict__ add, int add_f32, int ldadd, bf16_t* __restrict__ y, int ldy, int M, int D) {
   const int nv = D >> 2;
   const long total = (long)M * nv;
   for (long t = blockIdx.x * (long)blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
     const int m = (int)(t / nv), c = (int)(t % nv) * 4;
     f32x4 v = *(const f32x4*)(x + (size_t)map_row(xmap, m) * ldx + c);
     if (rowscale) v *= rowscale[m / rps];
-    if (add) v += *(const f32x4*)(add + (size_t)m * ldadd + c);
+    if (add) {
+      if (add_f32) v += *(const f32x4*)((const float*)add + (size_t)m * ldadd + c);
+      else {
+        const uint2 pa = *(const uint2*)((const bf16_t*)add + (size_t)m * ldadd + c);
+        v += f32x4{__uint_as_float(pa.x << 16), __uint_as_float(pa.x & 0xffff0000u), __uint_as_float(pa.y << 16),
+                   __uint_as_float(pa.y & 0xffff0000u)};
+      }
+    }
     uint2 pk = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
     *(uint2*)(y + (size_t)m * ldy + c) = pk;
   }
@@ -152,12 +159,13 @@ extern "C" int dkd_embed_bwd(const float* dx, float* dtok, float* dpos, int32_t 
 }
 
 extern "C" int dkd_scale_cast_bf16(const float* x, int32_t ldx, DkdRowMap xmap, const float* rowscale, int32_t rows_per_sample,
-                                   const float* add, int32_t ldadd, void* y, int32_t ldy, int32_t M, int32_t D, void* stream) {
+                                   const void* add, int32_t add_is_f32, int32_t ldadd, void* y, int32_t ldy, int32_t M, int32_t D,
+                                   void* stream) {
   DKD_CHECK_ARG(x && y, "scale_cast: null operand");
   DKD_CHECK_ARG(D % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && (!add || ldadd % 4 == 0), "scale_cast: D/ld must be multiples of 4");
   DKD_CHECK_ARG(!rowscale || rows_per_sample > 0, "scale_cast: rowscale needs rows_per_sample");
   hipLaunchKernelGGL(scale_cast_kernel, dim3(grid_for((long)M * D / 4)), dim3(256), 0, as_stream(stream), x, ldx, xmap, rowscale,
-                     rows_per_sample, add, ldadd, (bf16_t*)y, ldy, M, D);
+                     rows_per_sample, add, add_is_f32, ldadd, (bf16_t*)y, ldy, M, D);
   DKD_CHECK_LAUNCH("scale_cast");
   return DKD_OK;
 }

@@ -63,8 +63,8 @@ _SIGS = {
     "dkd_im2col_patches": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "dkd_prefix_tokens_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "dkd_embed_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
-    "dkd_scale_cast_bf16": (C.c_int, [C.c_void_p, C.c_int32, RowMap, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p,
-                                      C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "dkd_scale_cast_bf16": (C.c_int, [C.c_void_p, C.c_int32, RowMap, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32,
+                                      C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "dkd_cast_weight": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "dkd_colsum": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, RowMap, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "dkd_add_rows": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, RowMap, C.c_int32, C.c_int32, C.c_int32,

@@ -1,0 +1,243 @@
+"""Distillation losses on libdkd.so -- drop-in for /root/reference/model/loss.py.
+
+Same public surface: ``DistillationLoss(base_criterion, teacher_model, distillation_type, alpha, tau)`` called as
+``criterion(inputs, outputs, student_model, student_features, labels, args)`` (model/loss.py:19-29), ``call_base_loss``
+(:244-249) and the free functions ``lrkd_loss`` / ``mgd_loss`` (:314, :422).  Same error behaviour: ``ValueError`` for an
+unknown type (:238-239) or for soft/hard without a ``(logits, logits_kd)`` tuple (:39-42).
+
+What differs by design (MI355X-first):
+  * every loss is a fused value+gradient kernel (closed forms: SURVEY.md Appendix C); one autograd node per term.
+  * the teacher runs once, in inference mode, optionally on a side HIP stream (``teacher_stream``), writing only the taps
+    the branch consumes.
+  * LRKD's ``svd(T)`` (model/loss.py:321) becomes Gram (split-M MFMA wgrad kernel) -> symmetric eigendecomposition of the
+    [Dt, Dt] Gram matrix -> projection GEMM:  U_k S_k == T V_k up to the per-column sign LAPACK picks (SURVEY.md section 0
+    item 9: the reference's own CPU and CUDA runs disagree on that sign).
+  * prefix tokens stripped are each model's ``num_prefix_tokens`` (the reference hard-codes student 1 / teacher 2).
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .ffi import IDENT, RowMap, strip_map
+from .vit import BF16, F32, Linear, ensure_grad
+
+_KD_MODE = {"none": 0, "soft": 1, "hard": 2}
+
+
+def _unwrap(model):
+    while hasattr(model, "module") and isinstance(getattr(model, "module"), nn.Module):
+        model = model.module
+    return model
+
+
+# ----------------------------------------------------------------------------------------------- base criteria
+class _LogitLossFn(torch.autograd.Function):
+    """w_base * base(z, target) + w_kd * distill(z_kd, z_t): one launch computes both values and both gradients."""
+
+    @staticmethod
+    def forward(ctx, z, z_kd, target, z_t, kd_mode, smoothing, tau, w_base, w_kd):
+        losses, dz, dz_kd = ops.logit_loss(z.contiguous().float(), target, smoothing=smoothing, kd_mode=kd_mode,
+                                           z_kd=None if z_kd is None else z_kd.contiguous().float(),
+                                           z_t=None if z_t is None else z_t.contiguous().float(), tau=tau, w_base=w_base, w_kd=w_kd)
+        ctx.dz, ctx.dz_kd = dz, dz_kd
+        ctx.parts = losses
+        return w_base * losses[0] + w_kd * losses[1]
+
+    @staticmethod
+    def backward(ctx, g):
+        dz = ctx.dz * g
+        dz_kd = None if ctx.dz_kd is None else ctx.dz_kd * g
+        return dz, dz_kd, None, None, None, None, None, None, None
+
+
+def _prep_target(target, device):
+    if target.dtype in (torch.int32, torch.int64):
+        return target.to(device=device, dtype=torch.int64).contiguous()
+    return target.to(device=device, dtype=F32).contiguous()
+
+
+class SoftTargetCrossEntropy(nn.Module):
+    """timm.loss.SoftTargetCrossEntropy [3P]: mean_b sum_c -y log_softmax(z)."""
+
+    def forward(self, x, target):
+        return _LogitLossFn.apply(x, None, _prep_target(target, x.device), None, 0, 0.0, 1.0, 1.0, 0.0)
+
+
+class LabelSmoothingCrossEntropy(nn.Module):
+    """timm.loss.LabelSmoothingCrossEntropy [3P]: (1-eps) nll + eps mean_c(-logp)."""
+
+    def __init__(self, smoothing=0.1):
+        super().__init__()
+        self.smoothing = smoothing
+
+    def forward(self, x, target):
+        return _LogitLossFn.apply(x, None, _prep_target(target, x.device), None, 0, self.smoothing, 1.0, 1.0, 0.0)
+
+
+def call_base_loss(args):
+    """model/loss.py:244-249."""
+    mixup_active = args.mixup > 0 or args.cutmix > 0. or args.cutmix_minmax
+    return SoftTargetCrossEntropy() if mixup_active else LabelSmoothingCrossEntropy(smoothing=args.smoothing)
+
+
+# ----------------------------------------------------------------------------------------------- feature terms
+def _pad64(n):
+    return (n + 63) // 64 * 64
+
+
+class _AlignMseFn(torch.autograd.Function):
+    """scale * mean(mask * (align(tap[:, npre:]) - target)^2): align GEMM + fused MSE/dMSE; backward = dgrad + wgrad GEMMs.
+
+    tap: bf16 [B, N, Ds] (student block tap);  target: f32|bf16 [B*P, Dt] rows through ``tmap``.
+    """
+
+    @staticmethod
+    def forward(ctx, tap, align: Linear, shadow, target, tmap, scale, npre):
+        B, N, Ds = tap.shape
+        P = N - npre
+        M, Dt = B * P, align.out_features
+        tap2 = tap.reshape(B * N, Ds)
+        s = ops.gemm_nt(tap2, shadow.get(align.weight), M=M, amap=strip_map(N, npre), bias=align.bias, out_f32=True)
+        loss = torch.zeros(1, device=tap.device, dtype=F32)
+        if target.stride(-1) != 1:
+            target = target.contiguous()       # e.g. a column-major LAPACK result
+        Kp = _pad64(Dt)
+        da = torch.zeros(M, Kp, device=tap.device, dtype=BF16) if Kp != Dt else torch.empty(M, Kp, device=tap.device, dtype=BF16)
+        ops.mse_loss(s, target, loss, scale / (M * Dt), M=M, tmap=tmap, grad_out=da)
+        ctx.align, ctx.shadow, ctx.tap2, ctx.da, ctx.dims = align, shadow, tap2, da, (B, N, Ds, npre, M, Dt, Kp)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        B, N, Ds, npre, M, Dt, Kp = ctx.dims
+        align, da = ctx.align, ctx.da
+        da.mul_(g.to(BF16))
+        smap = strip_map(N, npre)
+        ops.gemm_tn(da, ctx.tap2, ensure_grad(align.weight), M=M, N1=Dt, bmap=smap)
+        ops.colsum(da, ensure_grad(align.bias), N=Dt)
+        dtap = torch.zeros(B * N, Ds, device=da.device, dtype=BF16)
+        ops.gemm_nt(da, ctx.shadow.get(align.weight, transposed=True, pad_k_to=Kp), out=dtap, cmap=smap)
+        ctx.da = ctx.tap2 = None
+        return dtap.view(B, N, Ds), None, None, None, None, None, None
+
+
+@torch.no_grad()
+def lrkd_targets(t_tap, npre, rank):
+    """U_k S_k of the [B*P, Dt] teacher matrix (model/loss.py:318-324) as T V_k; t_tap bf16 [B, N, Dt] -> f32 [B*P, rank]."""
+    B, N, Dt = t_tap.shape
+    P = N - npre
+    T = t_tap.reshape(B * N, Dt)
+    smap = strip_map(N, npre)
+    G = torch.zeros(Dt, Dt, device=T.device, dtype=F32)
+    ops.gemm_tn(T, T, G, M=B * P, amap=smap, bmap=smap)
+    G = 0.5 * (G + G.t())
+    _, evecs = torch.linalg.eigh(G)                       # ascending eigenvalues; [Dt, Dt] glue (hipSOLVER)
+    Vt = evecs[:, -rank:].flip(1).t().contiguous()        # [rank, Dt], descending singular values
+    hi = Vt.to(BF16)
+    lo = (Vt - hi.float()).to(BF16)                       # bf16 hi/lo split keeps ~16 bits of V through the bf16 MFMA
+    A = ops.gemm_nt(T, hi, M=B * P, amap=smap, out_f32=True)
+    ops.gemm_nt(T, lo, out=A, M=B * P, amap=smap, accumulate=True)
+    return A
+
+
+def lrkd_loss(teacher_features, student_features, rank=10, alpha=0.1, beta=0.1, gamma=0.1, *, student_model=None, npre_s=1,
+              npre_t=2, targets=None):
+    """model/loss.py:314-330.  ``student_features`` are the raw block taps (bf16 [B, N, Ds]); the align Linear of
+    model/loss.py:88-92 is fused into the term, so ``student_model`` (owner of ``align``) is required."""
+    if student_model is None:
+        raise ValueError("lrkd_loss needs student_model= (the align projections are fused into the loss kernels)")
+    sm = _unwrap(student_model)
+    total = None
+    for i, w in enumerate((alpha, beta, gamma)):
+        tgt = targets[i] if targets is not None else lrkd_targets(teacher_features[i], npre_t, rank)
+        term = _AlignMseFn.apply(student_features[i], sm.align[i], sm._shadow, tgt, IDENT, float(w), npre_s)
+        total = term if total is None else total + term
+    return total
+
+
+# ----------------------------------------------------------------------------------------------- the criterion
+class DistillationLoss(nn.Module):
+    def __init__(self, base_criterion, teacher_model, distillation_type, alpha, tau, teacher_stream=None):
+        super().__init__()
+        self.base_criterion = base_criterion
+        self.teacher_model = teacher_model
+        self.distillation_type = distillation_type
+        self.alpha = alpha
+        self.tau = tau
+        self.teacher_stream = teacher_stream
+        self.injected = {}          # parity tests inject random draws / precomputed targets here
+        self.last_parts = None
+
+    # which teacher block taps each branch consumes (model/loss.py:95-99,117-121,193,428)
+    _TAPS = {"lrkd": (0, 1, 11), "diffkd": (0, 1, -1), "wasskd": (0, 1, 2), "mgd": (-1,), "vitkd": (0, 1, -1),
+             "saliency_mgd": (-1,), "curkd": None}
+
+    @torch.no_grad()
+    def run_teacher(self, inputs, kind):
+        t = self.teacher_model
+        if kind in ("soft", "hard"):
+            return t(inputs), None
+        fwt = getattr(_unwrap(t), "forward_with_taps", None)
+        if fwt is None:
+            raise RuntimeError("teacher model has no forward_with_taps(); build it with deltakd_amd.vit.create_model")
+        return fwt(inputs, self._TAPS.get(kind))
+
+    def _base(self, outputs, labels, w_base, kd_mode=0, z_kd=None, z_t=None, w_kd=0.0):
+        crit = self.base_criterion
+        if isinstance(crit, (SoftTargetCrossEntropy, LabelSmoothingCrossEntropy)):
+            sm = crit.smoothing if isinstance(crit, LabelSmoothingCrossEntropy) else 0.0
+            return _LogitLossFn.apply(outputs, z_kd, _prep_target(labels, outputs.device), z_t, kd_mode, sm, self.tau, w_base, w_kd)
+        loss = crit(outputs, labels) * w_base          # foreign criterion: torch autograd handles it
+        if kd_mode:
+            dummy = torch.zeros(outputs.shape[0], dtype=torch.int64, device=outputs.device)
+            kd = _LogitLossFn.apply(z_kd.detach() * 0, z_kd, dummy, z_t, kd_mode, 0.0, self.tau, 0.0, w_kd)
+            loss = loss + kd
+        return loss
+
+    def forward(self, inputs, outputs, student_model, student_features, labels, args):
+        outputs_kd = None
+        if not isinstance(outputs, torch.Tensor):
+            outputs, outputs_kd = outputs
+        kind = self.distillation_type.lower()
+        if kind == "none":
+            return self._base(outputs, labels, 1.0)
+        if outputs_kd is None and kind in ("soft", "hard"):
+            raise ValueError("When knowledge distillation is enabled, the model is expected to return a Tuple[Tensor, Tensor] "
+                             "with the output of the class_token and the dist_token")
+        if kind not in ("soft", "hard", "lrkd", "mgd", "wasskd", "diffkd"):
+            raise ValueError(f"Invalid distillation type: {self.distillation_type}")
+
+        if self.teacher_stream is not None:
+            self.teacher_stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self.teacher_stream):
+                t_logits, t_taps = self.run_teacher(inputs, kind)
+            torch.cuda.current_stream().wait_stream(self.teacher_stream)
+        else:
+            t_logits, t_taps = self.run_teacher(inputs, kind)
+
+        a = self.alpha
+        if kind in ("soft", "hard"):
+            return self._base(outputs, labels, 1.0 - a, _KD_MODE[kind], outputs_kd, t_logits, a)
+
+        sm = _unwrap(student_model)
+        ps = getattr(sm, "num_prefix_tokens", 1)
+        pt = getattr(_unwrap(self.teacher_model), "num_prefix_tokens", 2)
+        if kind == "lrkd":
+            base = self._base(outputs, labels, 1.0 - a)
+            sel_s = [student_features[0], student_features[1], student_features[-1]]
+            sel_t = [t_taps[0], t_taps[1], t_taps[11]]
+            d = lrkd_loss(sel_t, sel_s, args.lrkd_rank, a * args.lrkd_alpha, a * args.lrkd_beta, a * args.lrkd_gamma,
+                          student_model=sm, npre_s=ps, npre_t=pt, targets=self.injected.get("lrkd_targets"))
+            return base + d
+        from . import losses_ext
+        if kind == "mgd":
+            return self._base(outputs, labels, 1.0) + losses_ext.mgd_loss(sm, student_features, t_taps, args, npre_s=ps, npre_t=pt,
+                                                                           noise=self.injected.get("noise"))
+        if kind == "wasskd":
+            if args.wasskd_type != "l1":
+                raise NotImplementedError("wasskd sinkhorn: geomloss is an unpinned third-party dependency (parity unpinned); "
+                                          "use --wasskd-type l1")
+            return self._base(outputs, labels, 1.0) + losses_ext.wasskd_l1_loss(sm, student_features, t_taps, 5.0, ps, pt)
+        return self._base(outputs, labels, 1.0 - a) + losses_ext.diffkd_loss(sm, student_features, t_taps, a, ps, pt, self.injected)

@@ -1,0 +1,104 @@
+"""Model factory + feature tap -- drop-in for /root/reference/model/models.py.
+
+``load_teacher_student_model`` (:59-178) and ``forward_with_features`` (:181-199) keep their signatures; the aux modules
+bolted onto the student keep their attribute names (align, mask_token, generation, denoise_fn, align_wasskd) because they
+define checkpoint keys.  Deliberate fixes, documented in DESIGN.md:
+  * ``forward_with_features`` looks through a data-parallel wrapper for the block list but calls the WRAPPER's forward
+    (the reference returns (None, None) for a DDP-wrapped student: SURVEY.md section 3.5);
+  * no forward hooks: the fc2 GEMM epilogue writes the ``block.mlp`` output as a second result.
+"""
+import torch
+import torch.nn as nn
+
+from . import vit
+from .vit import Linear
+
+DATASET_NUM_CLASSES = {"cifar-100": 100, "cifar-10": 10, "imagenet-1k": 1000, "imagenet-21k": 21843, "stanford_cars": 196,
+                       "caltech256": 256, "flowers": 102}     # dataset/datasets.py:10-46
+
+
+class Conv3x3(nn.Module):
+    """Parameter holder with nn.Conv2d(C, C, 3, padding=1)'s layout and default init (model/models.py:149-151)."""
+
+    def __init__(self, cin, cout):
+        super().__init__()
+        conv = nn.Conv2d(cin, cout, kernel_size=3, padding=1)
+        self.weight = nn.Parameter(conv.weight.detach().clone())
+        self.bias = nn.Parameter(conv.bias.detach().clone())
+
+
+class Generation(nn.Sequential):
+    """Conv3x3 - ReLU - Conv3x3 with nn.Sequential's key names ("0.weight", "2.weight")."""
+
+    def __init__(self, dim):
+        super().__init__(Conv3x3(dim, dim), nn.ReLU(inplace=True), Conv3x3(dim, dim))
+
+
+class DenoisingNetwork(nn.Module):
+    """model/models.py:103-121 (key names net.0 / net.2 / time_embed.0 / time_embed.2)."""
+
+    def __init__(self, dims):
+        super().__init__()
+        self.net = nn.Sequential(Linear(dims, dims * 2), nn.GELU(), Linear(dims * 2, dims), nn.Dropout(0.1))
+        self.time_embed = nn.Sequential(nn.Linear(1, dims), nn.GELU(), nn.Linear(dims, dims))
+        for m in (self.net[0], self.net[2]):       # nn.Linear default init, as the reference's nn.Linear layers get
+            ref = nn.Linear(m.in_features, m.out_features)
+            with torch.no_grad():
+                m.weight.copy_(ref.weight)
+                m.bias.copy_(ref.bias)
+
+
+def _linear_default(i, o):
+    """Linear holder with nn.Linear's default (kaiming-uniform) init, as the reference's aux nn.Linear layers get."""
+    m, ref = Linear(i, o), nn.Linear(i, o)
+    with torch.no_grad():
+        m.weight.copy_(ref.weight)
+        m.bias.copy_(ref.bias)
+    return m
+
+
+def attach_aux(student, teacher, distillation_type, args=None):
+    """Bolt the method-specific trainable modules onto the student (model/models.py:76-176)."""
+    kind = distillation_type.lower()
+    ds, dt = student.embed_dim, teacher.embed_dim
+    if kind == "lrkd":
+        student.align = nn.ModuleList([_linear_default(ds, args.lrkd_rank) for _ in range(3)])
+    elif kind in ("soft", "hard"):
+        if hasattr(student, "set_distilled_training"):
+            student.set_distilled_training(enable=True)
+    elif kind == "diffkd":
+        student.denoise_fn = DenoisingNetwork(dt)
+        student.align = nn.ModuleList([_linear_default(ds, dt) for _ in range(3)])
+    elif kind == "mgd":
+        student.align = _linear_default(ds, dt)
+        student.mask_token = nn.Parameter(torch.zeros(1, 1, dt))
+        student.generation = Generation(dt)
+    elif kind == "wasskd":
+        student.align_wasskd = nn.ModuleList([_linear_default(ds, dt) for _ in range(3)])
+    return student
+
+
+def load_teacher_student_model(teacher_model_name, student_model_name, drop_path_rate=0.1, args=None):
+    num_classes = DATASET_NUM_CLASSES[args.dataset]
+    extra = getattr(args, "model_kwargs", None) or {}
+    teacher_model = vit.create_model(teacher_model_name, pretrained=True, drop_path_rate=drop_path_rate, num_classes=num_classes,
+                                     checkpoint_path=getattr(args, "teacher_checkpoint", None), **extra)
+    student_model = vit.create_model(student_model_name, pretrained=False, drop_path_rate=drop_path_rate, num_classes=num_classes,
+                                     **extra)
+    teacher_model.eval()
+    for param in teacher_model.parameters():
+        param.requires_grad = False
+    attach_aux(student_model, teacher_model, args.distillation_type, args)
+    return teacher_model, student_model
+
+
+def forward_with_features(model, x):
+    """-> (model_output, [block.mlp output of every block]) ; (None, None) if the model has no ``blocks``."""
+    inner = model
+    while not hasattr(inner, "blocks") and hasattr(inner, "module"):
+        inner = inner.module
+    if not hasattr(inner, "blocks"):
+        return None, None
+    if inner is model:
+        return model.forward_with_taps(x)
+    return model(x, with_taps=True)     # data-parallel wrapper: its forward arms gradient sync, then taps come back

@@ -12,6 +12,7 @@ from .ffi import (EPI_ACCUM, EPI_BIAS, EPI_DGELU, EPI_GELU, EPI_OUT_F32, EPI_REL
                   check, lib, ptr, stream)
 
 BF16, F32 = torch.bfloat16, torch.float32
+PROBE = None     # list collecting (kernel, M, N, K, start_event, end_event) when bench.py samples kernel durations
 
 
 def _is_f32(t):
@@ -74,6 +75,13 @@ def gemm_nt(a, b, out=None, *, M=None, bias=None, gelu=False, dgelu=False, relu=
     if accumulate:
         epi |= EPI_ACCUM
     g.epi = epi
+    if PROBE is not None:          # bench.py: HIP events around this launch, on the stream it is launched on
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        check(lib().dkd_gemm_nt(C.byref(g), stream()), "gemm_nt")
+        e1.record()
+        PROBE.append(("gemm_nt", M, N, K, e0, e1))
+        return out
     check(lib().dkd_gemm_nt(C.byref(g), stream()), "gemm_nt")
     return out
 
@@ -151,7 +159,8 @@ def scale_cast_bf16(x, *, M=None, xmap=IDENT, rowscale=None, rows_per_sample=0, 
     ld = ld_out or D
     y = torch.empty(M, ld, device=x.device, dtype=BF16) if ld == D else torch.zeros(M, ld, device=x.device, dtype=BF16)
     check(lib().dkd_scale_cast_bf16(ptr(x), x.stride(0), xmap, ptr(rowscale), rows_per_sample, ptr(add),
-                                    add.stride(0) if add is not None else 0, ptr(y), ld, M, D, stream()), "scale_cast")
+                                    _is_f32(add) if add is not None else 1, add.stride(0) if add is not None else 0, ptr(y), ld,
+                                    M, D, stream()), "scale_cast")
     return y
 
 
@@ -195,13 +204,21 @@ def logit_loss(z, target, *, smoothing=0.1, kd_mode=0, z_kd=None, z_t=None, tau=
     return losses, dz, dz_kd
 
 
-def mse_loss(a, t, loss, w_over_denom, *, M=None, tmap=IDENT, mask=None, grad=True, grad_f32=False):
-    """loss[0] += w/denom * sum(mask (a - t)^2); returns d loss / d a (same shape as a) or None."""
+def mse_loss(a, t, loss, w_over_denom, *, M=None, tmap=IDENT, mask=None, grad=True, grad_f32=False, grad_out=None):
+    """loss[0] += w/denom * sum(mask (a - t)^2); returns d loss / d a ([M, D], bf16 unless grad_f32) or None.
+
+    ``grad_out``: preallocated gradient buffer (its dtype and row stride are used; lets the caller K-pad it).
+    """
     M = a.shape[0] if M is None else M
     D = a.shape[1]
-    da = torch.empty(M, D, device=a.device, dtype=F32 if grad_f32 else BF16) if grad else None
+    assert a.stride(1) == 1 and t.stride(1) == 1, "mse_loss operands must be row-major"
+    if grad_out is not None:
+        da = grad_out
+    else:
+        da = torch.empty(M, D, device=a.device, dtype=F32 if grad_f32 else BF16) if grad else None
     check(lib().dkd_mse_loss(ptr(a), _is_f32(a), a.stride(0), ptr(t), _is_f32(t), t.stride(0), tmap, ptr(mask), w_over_denom,
-                             ptr(loss), ptr(da), int(grad_f32), D, M, D, stream()), "mse_loss")
+                             ptr(loss), ptr(da), _is_f32(da) if da is not None else 0, da.stride(0) if da is not None else 0,
+                             M, D, stream()), "mse_loss")
     return da
 
 

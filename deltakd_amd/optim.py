@@ -1,0 +1,180 @@
+"""Fused AdamW over flat parameter storage + timm-compatible factories.
+
+Replaces ``timm.optim.create_optimizer`` / ``timm.scheduler.create_scheduler`` ([3P], /root/reference/tools/train.py:264-266)
+and the multi-tensor torch AdamW they build.  MI355X-first layout: all trainable parameters live in ONE fp32 buffer
+(the module's ``nn.Parameter``s become views of it), gradients in a second flat buffer (``p.grad`` views), so
+
+  * one AdamW launch per weight-decay group (2 per step) instead of a foreach chain, and the same launch refreshes the
+    bf16 shadow copies the MFMA GEMMs read (``Shadow.bind_flat``);
+  * ``zero_grad`` is one memset and keeps the gradient buffers alive (the kernels accumulate straight into ``p.grad``);
+  * data-parallel gradient averaging is an all-reduce over contiguous slices of one buffer (deltakd_amd.ddp).
+
+Update rule = torch.optim.AdamW (decoupled weight decay, bias correction), checked against it in tests.
+"""
+import math
+
+import torch
+
+from . import ops
+
+BF16, F32 = torch.bfloat16, torch.float32
+
+
+def param_groups_weight_decay(model, weight_decay, no_weight_decay_list=()):
+    """timm.optim.param_groups_weight_decay [3P]: 1-D params, biases and the model's no_weight_decay() set get wd 0."""
+    no_weight_decay_list = set(no_weight_decay_list)
+    decay, no_decay = [], []
+    for name, param in model.named_parameters():
+        if not param.requires_grad:
+            continue
+        if param.ndim <= 1 or name.endswith(".bias") or name in no_weight_decay_list:
+            no_decay.append(param)
+        else:
+            decay.append(param)
+    return [{"params": no_decay, "weight_decay": 0.}, {"params": decay, "weight_decay": weight_decay}]
+
+
+class FusedAdamW(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, shadows=()):
+        defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
+        super().__init__(params, defaults)
+        self._shadows = list(shadows)
+        self._flat = []
+        self._step = 0
+        self.grad_sync = None          # set by deltakd_amd.ddp: called with the flat grad buffers before the update
+        self._flatten()
+
+    def _flatten(self):
+        bound = {}
+        for group in self.param_groups:
+            ps = [p for p in group["params"] if p.requires_grad]
+            if not ps:
+                self._flat.append(None)
+                continue
+            dev = ps[0].device
+            if dev.type != "cuda":
+                raise RuntimeError("FusedAdamW needs parameters on an MI355X device (move the model first; no CPU path)")
+            sizes = [(p.numel() + 7) // 8 * 8 for p in ps]          # keep every f32 AND bf16 view 16-byte aligned
+            total = sum(sizes)
+            fp = torch.zeros(total, device=dev, dtype=F32)
+            fg = torch.zeros(total, device=dev, dtype=F32)
+            fb = torch.zeros(total, device=dev, dtype=BF16)
+            off = 0
+            for p, n in zip(ps, sizes):
+                k = p.numel()
+                fp[off:off + k].copy_(p.detach().reshape(-1))
+                old_grad = p.grad
+                p.data = fp[off:off + k].view(p.shape)
+                p.grad = fg[off:off + k].view(p.shape)
+                if old_grad is not None:
+                    p.grad.copy_(old_grad)
+                bound[id(p)] = fb[off:off + k]
+                off += n
+            fb.copy_(fp)
+            self._flat.append(dict(p=fp, g=fg, bf=fb, m=torch.zeros_like(fp), v=torch.zeros_like(fp)))
+        for sh in self._shadows:
+            sh.bind_flat(bound)
+            sh.optimizer_stepped(bf16_fresh=True)
+
+    @property
+    def flat_grads(self):
+        return [f["g"] for f in self._flat if f is not None]
+
+    def zero_grad(self, set_to_none=False):
+        for f in self._flat:
+            if f is not None:
+                f["g"].zero_()
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        if closure is not None:
+            raise NotImplementedError("FusedAdamW does not take a closure")
+        if self.grad_sync is not None:
+            self.grad_sync(self.flat_grads)
+        self._step += 1
+        for group, f in zip(self.param_groups, self._flat):
+            if f is None:
+                continue
+            b1, b2 = group["betas"]
+            ops.adamw_step(f["p"], f["g"], f["m"], f["v"], f["bf"], group["lr"], b1, b2, group["eps"], group["weight_decay"],
+                           self._step)
+        for sh in self._shadows:
+            sh.optimizer_stepped(bf16_fresh=True)
+
+    def state_dict(self):
+        return {"step": self._step,
+                "flat": [None if f is None else {k: f[k].detach().cpu() for k in ("m", "v")} for f in self._flat],
+                "param_groups": [{k: v for k, v in g.items() if k != "params"} for g in self.param_groups]}
+
+    def load_state_dict(self, sd):
+        self._step = sd["step"]
+        for f, s in zip(self._flat, sd["flat"]):
+            if f is not None and s is not None:
+                f["m"].copy_(s["m"])
+                f["v"].copy_(s["v"])
+        for g, s in zip(self.param_groups, sd["param_groups"]):
+            g.update(s)
+
+
+def _shadows_of(model):
+    return [m._shadow for m in model.modules() if hasattr(m, "_shadow")]
+
+
+def create_optimizer(args, model, filter_bias_and_bn=True):
+    """timm.optim.create_optimizer(args, model) [3P] for ``--opt adamw`` (the only optimizer the exp/*.sh scripts use)."""
+    opt = getattr(args, "opt", "adamw").lower()
+    if opt != "adamw":
+        raise ValueError(f"deltakd_amd.optim supports --opt adamw (got {opt!r})")
+    wd = args.weight_decay
+    inner = model.module if hasattr(model, "module") else model
+    if wd and filter_bias_and_bn:
+        skip = inner.no_weight_decay() if hasattr(inner, "no_weight_decay") else ()
+        groups = param_groups_weight_decay(inner, wd, skip)
+        wd = 0.
+    else:
+        groups = [{"params": [p for p in inner.parameters() if p.requires_grad]}]
+    kw = dict(lr=args.lr, weight_decay=wd, eps=getattr(args, "opt_eps", None) or 1e-8)
+    if getattr(args, "opt_betas", None):
+        kw["betas"] = tuple(args.opt_betas)
+    return FusedAdamW(groups, shadows=_shadows_of(inner), **kw)
+
+
+class CosineLRScheduler:
+    """timm.scheduler.CosineLRScheduler [3P] as ``create_scheduler`` configures it (t_in_epochs, one cycle, linear warm-up)."""
+
+    def __init__(self, optimizer, t_initial, lr_min=0., warmup_t=0, warmup_lr_init=0.):
+        self.optimizer = optimizer
+        self.t_initial, self.lr_min, self.warmup_t, self.warmup_lr_init = t_initial, lr_min, warmup_t, warmup_lr_init
+        self.base_values = [g["lr"] for g in optimizer.param_groups]
+        for g, v in zip(optimizer.param_groups, self.base_values):
+            g.setdefault("initial_lr", v)
+        self._set([warmup_lr_init] * len(self.base_values) if warmup_t else self.base_values)
+
+    def _set(self, values):
+        for g, v in zip(self.optimizer.param_groups, values):
+            g["lr"] = v
+
+    def _get_lr(self, t):
+        if t < self.warmup_t:
+            return [self.warmup_lr_init + t * (v - self.warmup_lr_init) / self.warmup_t for v in self.base_values]
+        if t < self.t_initial:
+            return [self.lr_min + 0.5 * (v - self.lr_min) * (1 + math.cos(math.pi * t / self.t_initial)) for v in self.base_values]
+        return [self.lr_min for _ in self.base_values]
+
+    def step(self, epoch, metric=None):
+        self._set(self._get_lr(epoch))
+
+    def state_dict(self):
+        return {k: v for k, v in self.__dict__.items() if k != "optimizer"}
+
+    def load_state_dict(self, sd):
+        self.__dict__.update(sd)
+
+
+def create_scheduler(args, optimizer):
+    """timm.scheduler.create_scheduler(args, optimizer) [3P] for ``--sched cosine`` -> (scheduler, num_epochs)."""
+    if getattr(args, "sched", "cosine") != "cosine":
+        raise ValueError("deltakd_amd.optim supports --sched cosine")
+    sched = CosineLRScheduler(optimizer, t_initial=args.epochs, lr_min=getattr(args, "min_lr", 1e-5),
+                              warmup_t=getattr(args, "warmup_epochs", 5), warmup_lr_init=getattr(args, "warmup_lr", 1e-6))
+    return sched, args.epochs + getattr(args, "cooldown_epochs", 10)

@@ -1,0 +1,96 @@
+"""Counterparts of the timm utilities the reference's step loop imports ([3P] timm==0.9.12; absent on the MI355X boxes):
+``timm.utils.accuracy`` / ``NativeScaler`` (tools/engine.py:3, tools/train.py:11) and ``timm.data.Mixup`` (tools/train.py:7).
+Host-side plumbing on torch tensors (they work on host or device tensors alike); the arithmetic that matters is in libdkd.
+"""
+import numpy as np
+import torch
+
+
+def accuracy(output, target, topk=(1,)):
+    """top-k accuracy in percent as 0-dim tensors (timm.utils.accuracy)."""
+    maxk = min(max(topk), output.size(1))
+    batch = target.size(0)
+    _, pred = output.topk(maxk, 1, True, True)
+    correct = pred.t().eq(target.reshape(1, -1).expand(maxk, -1))
+    return [correct[:min(k, maxk)].reshape(-1).float().sum(0) * 100. / batch for k in topk]
+
+
+class NativeScaler:
+    """timm.utils.NativeScaler's call contract: ``scaler(loss, optimizer, clip_grad=, parameters=, create_graph=)`` runs
+    backward, optional grad-norm clipping, and the optimizer step.  The bf16 MFMA path keeps fp32's exponent range, so no
+    loss scaling is applied (the reference's GradScaler is itself inert without ``--amp``)."""
+    state_dict_key = "amp_scaler"
+
+    def __call__(self, loss, optimizer, clip_grad=None, clip_mode="norm", parameters=None, create_graph=False, need_update=True):
+        loss.backward(create_graph=create_graph)
+        if need_update:
+            if clip_grad is not None:
+                assert parameters is not None
+                torch.nn.utils.clip_grad_norm_([p for p in parameters if p.grad is not None], clip_grad)
+            optimizer.step()
+
+    def state_dict(self):
+        return {}
+
+    def load_state_dict(self, state_dict):
+        pass
+
+
+def _one_hot(x, num_classes, on_value, off_value):
+    x = x.long().view(-1, 1)
+    return torch.full((x.size(0), num_classes), off_value, device=x.device).scatter_(1, x, on_value)
+
+
+def mixup_target(target, num_classes, lam=1., smoothing=0.0):
+    off = smoothing / num_classes
+    on = 1. - smoothing + off
+    return _one_hot(target, num_classes, on, off) * lam + _one_hot(target.flip(0), num_classes, on, off) * (1. - lam)
+
+
+class Mixup:
+    """timm.data.Mixup, mode='batch' (the mode every exp/*.sh uses): one lambda ~ Beta per batch from numpy's global RNG,
+    CutMix with probability ``switch_prob`` (random box, lambda corrected to the box area), label-smoothed soft targets."""
+
+    def __init__(self, mixup_alpha=1., cutmix_alpha=0., cutmix_minmax=None, prob=1.0, switch_prob=0.5, mode="batch",
+                 correct_lam=True, label_smoothing=0.1, num_classes=1000):
+        if mode != "batch":
+            raise ValueError("deltakd_amd.shims.Mixup implements mode='batch'")
+        if cutmix_minmax is not None:
+            raise ValueError("cutmix_minmax is not supported")
+        self.mixup_alpha, self.cutmix_alpha = mixup_alpha, cutmix_alpha
+        self.mix_prob, self.switch_prob = prob, switch_prob
+        self.label_smoothing, self.num_classes, self.correct_lam = label_smoothing, num_classes, correct_lam
+        self.mixup_enabled = True
+
+    def _params_per_batch(self):
+        lam, use_cutmix = 1., False
+        if self.mixup_enabled and np.random.rand() < self.mix_prob:
+            if self.mixup_alpha > 0. and self.cutmix_alpha > 0.:
+                use_cutmix = np.random.rand() < self.switch_prob
+                a = self.cutmix_alpha if use_cutmix else self.mixup_alpha
+                lam = float(np.random.beta(a, a))
+            elif self.mixup_alpha > 0.:
+                lam = float(np.random.beta(self.mixup_alpha, self.mixup_alpha))
+            elif self.cutmix_alpha > 0.:
+                use_cutmix = True
+                lam = float(np.random.beta(self.cutmix_alpha, self.cutmix_alpha))
+        return lam, use_cutmix
+
+    def __call__(self, x, target):
+        assert len(x) % 2 == 0, "Batch size should be even when using this"
+        lam, use_cutmix = self._params_per_batch()
+        if lam != 1.:
+            if use_cutmix:
+                H, W = x.shape[-2:]
+                ratio = np.sqrt(1 - lam)
+                ch, cw = int(H * ratio), int(W * ratio)
+                cy, cx = np.random.randint(0, H), np.random.randint(0, W)
+                yl, yh = np.clip(cy - ch // 2, 0, H), np.clip(cy + ch // 2, 0, H)
+                xl, xh = np.clip(cx - cw // 2, 0, W), np.clip(cx + cw // 2, 0, W)
+                if self.correct_lam:
+                    lam = 1. - (yh - yl) * (xh - xl) / float(H * W)
+                x[:, :, yl:yh, xl:xh] = x.flip(0)[:, :, yl:yh, xl:xh]
+            else:
+                x_flipped = x.flip(0).mul_(1. - lam)
+                x.mul_(lam).add_(x_flipped)
+        return x, mixup_target(target, self.num_classes, lam, self.label_smoothing)

@@ -1,0 +1,461 @@
+"""ViT / DeiT on libdkd.so -- the models behind ``timm.create_model`` at /root/reference/model/models.py:60-68.
+
+timm is absent on the MI355X boxes, so the product owns the model definitions.  Parameter names equal
+timm==0.9.12's state-dict keys (cls_token, dist_token, pos_embed, patch_embed.proj.*, blocks.N.norm1.*,
+blocks.N.attn.qkv.*, blocks.N.attn.proj.*, blocks.N.norm2.*, blocks.N.mlp.fc1.*, blocks.N.mlp.fc2.*, norm.*, head.*,
+head_dist.*) so real checkpoints load from a local file.
+
+Execution model (MI355X-first, not a module-per-op graph):
+  * fp32 master parameters; bf16 shadow copies W and W^T feed the MFMA GEMMs (W^T turns every dgrad into the same
+    K-contiguous NT kernel); the fp32 residual stream never leaves fp32.
+  * ONE autograd node per transformer block (``_BlockFn``): forward = 7 kernel launches (LN, qkv GEMM+bias, attention,
+    proj GEMM+bias+DropPath+residual, LN, fc1 GEMM+bias+GELU, fc2 GEMM+bias+tap+DropPath+residual); backward = 19.
+    Parameter gradients are accumulated by the kernels straight into ``p.grad`` (atomics / split-M wgrad), so the
+    nodes return no parameter gradients and ``zero_grad`` must zero, not drop, the grads
+    (``deltakd_amd.optim`` does; ``ensure_grads`` allocates them otherwise).
+  * the per-block feature tap of model/models.py:185-193 (``block.mlp`` output, before DropPath / residual) is written
+    by the fc2 GEMM epilogue as a second output of the same kernel -- no forward hooks, no extra pass.
+"""
+import math
+from typing import List, Optional, Sequence
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .ffi import IDENT, RowMap, strip_map
+
+BF16, F32 = torch.bfloat16, torch.float32
+
+REGISTRY = {
+    # name: (embed_dim, depth, heads, distilled)            [timm registry, SURVEY.md Appendix B]
+    "deit_tiny_patch16_224": (192, 12, 3, False),
+    "deit_small_patch16_224": (384, 12, 6, False),
+    "deit_base_patch16_224": (768, 12, 12, False),
+    "deit_tiny_distilled_patch16_224": (192, 12, 3, True),
+    "deit_small_distilled_patch16_224": (384, 12, 6, True),
+    "deit_base_distilled_patch16_224": (768, 12, 12, True),
+    "vit_large_patch16_224": (1024, 24, 16, False),
+}
+
+
+def _trunc_normal_(t, std=0.02):
+    return nn.init.trunc_normal_(t, mean=0.0, std=std, a=-2.0, b=2.0)
+
+
+def ensure_grad(p: torch.Tensor) -> torch.Tensor:
+    """Parameter gradients are written in place by the kernels: make sure the buffer exists (zero-filled)."""
+    if p.grad is None:
+        p.grad = torch.zeros_like(p)
+    return p.grad
+
+
+class Shadow:
+    """bf16 copies (W, optionally W^T, optionally K-padded) of fp32 master weights, refreshed when the master changes.
+
+    Staleness is detected from torch's version counter (in-place optimizer updates bump it) plus ``generation``, which the
+    fused optimizer bumps because its kernel updates the masters behind torch's back.  When the fused optimizer is bound
+    (``bind_flat``) it refreshes the plain bf16 copies itself, inside the AdamW kernel, and only W^T needs a launch here.
+    """
+
+    def __init__(self):
+        self._slots = {}
+        self._bound = {}          # id(param) -> bf16 view kept fresh by FusedAdamW
+        self.generation = 0
+        self.bound_generation = -1
+
+    def bind_flat(self, views):
+        self._bound = dict(views)
+        self._slots.clear()
+
+    def optimizer_stepped(self, bf16_fresh: bool):
+        self.generation += 1
+        if bf16_fresh:
+            self.bound_generation = self.generation
+
+    def get(self, p: torch.Tensor, transposed=False, pad_k_to=0):
+        key = (id(p), transposed, pad_k_to)
+        slot = self._slots.get(key)
+        stamp = (self.generation, p._version, p.data_ptr())
+        if slot is not None and slot[0] == stamp:
+            return slot[1]
+        w2 = p.detach().reshape(p.shape[0], -1)
+        rows, cols = w2.shape
+        if not transposed:
+            bound = self._bound.get(id(p))
+            if bound is not None and self.bound_generation == self.generation:
+                buf = bound.view(rows, cols)                      # already refreshed by the AdamW kernel
+            else:
+                buf = slot[1] if slot else (bound.view(rows, cols) if bound is not None else
+                                            torch.empty(rows, cols, device=p.device, dtype=BF16))
+                ops.cast_weight(w2, buf, None)
+        else:
+            ld = max(rows, pad_k_to)
+            if ld != rows:   # K-padded transpose (dgrad whose K = out_features is not a multiple of 64)
+                buf = slot[1] if slot else torch.zeros(cols, ld, device=p.device, dtype=BF16)
+                tmp = torch.empty(cols, rows, device=p.device, dtype=BF16)
+                ops.cast_weight(w2, None, tmp)
+                buf[:, :rows].copy_(tmp)
+            else:
+                buf = slot[1] if slot else torch.empty(cols, rows, device=p.device, dtype=BF16)
+                ops.cast_weight(w2, None, buf)
+        self._slots[key] = (stamp, buf)
+        return buf
+
+    def clear(self):
+        self._slots.clear()
+        self._bound = {}
+
+
+# ----------------------------------------------------------------------------------------------- parameter holders
+class Linear(nn.Module):
+    """Parameter holder with nn.Linear's layout (weight [out, in], bias [out]); callable on bf16 token matrices."""
+
+    def __init__(self, in_features, out_features, bias=True):
+        super().__init__()
+        self.in_features, self.out_features = in_features, out_features
+        self.weight = nn.Parameter(torch.empty(out_features, in_features))
+        self.bias = nn.Parameter(torch.zeros(out_features)) if bias else None
+        _trunc_normal_(self.weight, std=.02)
+
+    def extra_repr(self):
+        return f"{self.in_features}, {self.out_features}"
+
+
+class LayerNormP(nn.Module):
+    def __init__(self, dim, eps=1e-6):
+        super().__init__()
+        self.eps = eps
+        self.weight = nn.Parameter(torch.ones(dim))
+        self.bias = nn.Parameter(torch.zeros(dim))
+
+
+class _ConvP(nn.Module):
+    def __init__(self, cin, cout, k):
+        super().__init__()
+        conv = nn.Conv2d(cin, cout, k, k)            # PyTorch's default Conv2d init, like timm's PatchEmbed
+        self.weight = nn.Parameter(conv.weight.detach().clone())
+        self.bias = nn.Parameter(conv.bias.detach().clone())
+
+
+class PatchEmbed(nn.Module):
+    def __init__(self, img_size, patch, in_chans, dim):
+        super().__init__()
+        self.img_size, self.patch_size = img_size, patch
+        self.num_patches = (img_size // patch) ** 2
+        self.proj = _ConvP(in_chans, dim, patch)
+
+
+class Attention(nn.Module):
+    def __init__(self, dim, heads):
+        super().__init__()
+        assert dim == heads * 64, "the attention kernels are built for head_dim 64 (every model in scope)"
+        self.num_heads = heads
+        self.qkv = Linear(dim, dim * 3)
+        self.proj = Linear(dim, dim)
+
+
+class Mlp(nn.Module):
+    def __init__(self, dim, hidden):
+        super().__init__()
+        self.fc1 = Linear(dim, hidden)
+        self.fc2 = Linear(hidden, dim)
+
+
+class Block(nn.Module):
+    def __init__(self, dim, heads, mlp_ratio, drop_path):
+        super().__init__()
+        self.norm1 = LayerNormP(dim)
+        self.attn = Attention(dim, heads)
+        self.norm2 = LayerNormP(dim)
+        self.mlp = Mlp(dim, int(dim * mlp_ratio))
+        self.drop_prob = float(drop_path)
+
+
+# ----------------------------------------------------------------------------------------------- block kernels
+def _block_forward(x, B, N, blk: Block, sh: Shadow, s1, s2, save: bool, want_tap: bool, inplace: bool):
+    """x f32 [B*N, D] -> (x2, tap, saved).  s1/s2: per-sample DropPath scale f32 [B] or None."""
+    H = blk.attn.num_heads
+    M, D = x.shape
+    y1, mean1, rstd1 = ops.layernorm_fwd(x, blk.norm1.weight, blk.norm1.bias, save_stats=save)
+    qkv = ops.gemm_nt(y1, sh.get(blk.attn.qkv.weight), bias=blk.attn.qkv.bias)
+    o, lse = ops.attn_fwd(qkv, B, N, H, need_lse=save)
+    x1 = ops.gemm_nt(o, sh.get(blk.attn.proj.weight), out=x if inplace else None, bias=blk.attn.proj.bias, resid=x, rowscale=s1,
+                     rows_per_sample=N, out_f32=True)
+    y2, mean2, rstd2 = ops.layernorm_fwd(x1, blk.norm2.weight, blk.norm2.bias, save_stats=save)
+    pre = torch.empty(M, blk.mlp.fc1.out_features, device=x.device, dtype=BF16) if save else None
+    h = ops.gemm_nt(y2, sh.get(blk.mlp.fc1.weight), bias=blk.mlp.fc1.bias, gelu=True, preact=pre)
+    tap = torch.empty(M, D, device=x.device, dtype=BF16) if want_tap else None
+    x2 = ops.gemm_nt(h, sh.get(blk.mlp.fc2.weight), out=x1 if inplace else None, bias=blk.mlp.fc2.bias, resid=x1, rowscale=s2,
+                     rows_per_sample=N, tap=tap, out_f32=True)
+    saved = (x, y1, mean1, rstd1, qkv, o, lse, x1, y2, mean2, rstd2, pre, h) if save else None
+    return x2, tap, saved
+
+
+def _block_backward(g, gtap, B, N, blk: Block, sh: Shadow, s1, s2, saved):
+    """g: f32 [B*N, D] gradient w.r.t. the block output (modified in place and returned as the input gradient)."""
+    x, y1, mean1, rstd1, qkv, o, lse, x1, y2, mean2, rstd2, pre, h = saved
+    H = blk.attn.num_heads
+    fc1, fc2, proj, qkvl = blk.mlp.fc1, blk.mlp.fc2, blk.attn.proj, blk.attn.qkv
+    # ---- MLP branch: x2 = x1 + s2 * (fc2(gelu(fc1(LN2(x1)))));  tap = fc2 output
+    dF = ops.scale_cast_bf16(g, rowscale=s2, rows_per_sample=N, add=gtap)
+    ops.gemm_tn(dF, h, ensure_grad(fc2.weight))
+    ops.colsum(dF, ensure_grad(fc2.bias))
+    dH = ops.gemm_nt(dF, sh.get(fc2.weight, transposed=True), dgelu=True, preact=pre)
+    ops.gemm_tn(dH, y2, ensure_grad(fc1.weight))
+    ops.colsum(dH, ensure_grad(fc1.bias))
+    dY2 = ops.gemm_nt(dH, sh.get(fc1.weight, transposed=True))
+    ops.layernorm_bwd(dY2, x1, blk.norm2.weight, mean2, rstd2, g, ensure_grad(blk.norm2.weight), ensure_grad(blk.norm2.bias),
+                      accumulate=True)
+    # ---- attention branch: x1 = x + s1 * proj(attn(qkv(LN1(x))))
+    dA = ops.scale_cast_bf16(g, rowscale=s1, rows_per_sample=N)
+    ops.gemm_tn(dA, o, ensure_grad(proj.weight))
+    ops.colsum(dA, ensure_grad(proj.bias))
+    dO = ops.gemm_nt(dA, sh.get(proj.weight, transposed=True))
+    dqkv = ops.attn_bwd(qkv, o, dO, lse, B, N, H)
+    ops.gemm_tn(dqkv, y1, ensure_grad(qkvl.weight))
+    ops.colsum(dqkv, ensure_grad(qkvl.bias))
+    dY1 = ops.gemm_nt(dqkv, sh.get(qkvl.weight, transposed=True))
+    ops.layernorm_bwd(dY1, x, blk.norm1.weight, mean1, rstd1, g, ensure_grad(blk.norm1.weight), ensure_grad(blk.norm1.bias),
+                      accumulate=True)
+    return g
+
+
+class _BlockFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, model, idx, B, N, s1, s2, want_tap):
+        blk = model.blocks[idx]
+        ctx.set_materialize_grads(False)     # an unused tap must not cost a zero-filled [M, D] gradient
+        x2, tap, saved = _block_forward(x, B, N, blk, model._shadow, s1, s2, True, want_tap, False)
+        ctx.model, ctx.idx, ctx.B, ctx.N, ctx.s1, ctx.s2 = model, idx, B, N, s1, s2
+        ctx.saved = saved
+        if tap is None:
+            tap = x2.new_empty(0)
+            ctx.mark_non_differentiable(tap)
+        return x2, tap
+
+    @staticmethod
+    def backward(ctx, g, gtap):
+        if ctx.saved is None:
+            raise RuntimeError("deltakd_amd block: backward called twice (activations are released after the first pass)")
+        if gtap is not None and gtap.numel() == 0:
+            gtap = None
+        if gtap is not None:
+            gtap = gtap.contiguous()
+        if g is None:
+            g = torch.zeros_like(ctx.saved[0])
+        g = g.contiguous()
+        if g.dtype != F32:
+            g = g.float()
+        blk = ctx.model.blocks[ctx.idx]
+        gin = _block_backward(g, gtap, ctx.B, ctx.N, blk, ctx.model._shadow, ctx.s1, ctx.s2, ctx.saved)
+        ctx.saved = None
+        return gin, None, None, None, None, None, None, None
+
+
+class _EmbedFn(torch.autograd.Function):
+    """patch-embed GEMM (+bias +pos_embed, scattered behind the prefix tokens) and prefix-token assembly."""
+
+    @staticmethod
+    def forward(ctx, anchor, model, img):
+        x, patches = model._embed(img)
+        ctx.model, ctx.patches, ctx.B = model, patches, img.shape[0]
+        return x
+
+    @staticmethod
+    def backward(ctx, g):
+        m = ctx.model
+        B, N, D, npre = ctx.B, m.num_tokens, m.embed_dim, m.num_prefix_tokens
+        P = N - npre
+        g = g.contiguous()
+        dxb = ops.scale_cast_bf16(g, M=B * P, xmap=strip_map(N, npre))
+        w = m.patch_embed.proj.weight
+        ops.gemm_tn(dxb, ctx.patches, ensure_grad(w).view(D, -1))
+        ops.colsum(dxb, ensure_grad(m.patch_embed.proj.bias))
+        dtok = torch.zeros(npre, D, device=g.device, dtype=F32)
+        ops.embed_bwd(g, dtok, ensure_grad(m.pos_embed).view(N, D), B, N, D, npre)
+        ensure_grad(m.cls_token).view(-1).add_(dtok[0])
+        if npre == 2:
+            ensure_grad(m.dist_token).view(-1).add_(dtok[1])
+        ctx.patches = None
+        return None, None, None
+
+
+class _HeadFn(torch.autograd.Function):
+    """final LayerNorm on the prefix tokens + classifier head(s); logits f32 [B, C] (x npre)."""
+
+    @staticmethod
+    def forward(ctx, x, model, B):
+        m = model
+        N, D, npre = m.num_tokens, m.embed_dim, m.num_prefix_tokens
+        pmap = RowMap(npre, N, 0)
+        ctx.set_materialize_grads(False)
+        y, mean, rstd = ops.layernorm_fwd(x, m.norm.weight, m.norm.bias, M=B * npre, xmap=pmap)
+        outs = []
+        heads = [m.head] + ([m.head_dist] if m.distilled else [])
+        for t, hd in enumerate(heads):
+            outs.append(ops.gemm_nt(y, m._shadow.get(hd.weight), M=B, amap=RowMap(1, npre, t), bias=hd.bias, out_f32=True))
+        ctx.model, ctx.B = m, B
+        ctx.saved = (x, y, mean, rstd)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gz):
+        m, B = ctx.model, ctx.B
+        x, y, mean, rstd = ctx.saved
+        N, D, npre, C = m.num_tokens, m.embed_dim, m.num_prefix_tokens, m.num_classes
+        Cp = (C + 63) // 64 * 64
+        heads = [m.head] + ([m.head_dist] if m.distilled else [])
+        dy = torch.zeros(B * npre, D, device=x.device, dtype=F32)
+        for t, hd in enumerate(heads):
+            if gz[t] is None:
+                continue
+            dz = torch.zeros(B, Cp, device=x.device, dtype=BF16)
+            dz[:, :C] = gz[t]
+            ops.gemm_tn(dz, y, ensure_grad(hd.weight), M=B, N1=C, bmap=RowMap(1, npre, t))
+            ops.colsum(dz, ensure_grad(hd.bias), N=C)
+            # d y[b, t, :] = dz[b, :] @ W  (NT against the K-padded W^T shadow), scattered to row b*npre + t
+            ops.gemm_nt(dz, m._shadow.get(hd.weight, transposed=True, pad_k_to=Cp), out=dy, cmap=RowMap(1, npre, t))
+        g = torch.zeros_like(x)
+        ops.layernorm_bwd(dy, x, m.norm.weight, mean, rstd, g, ensure_grad(m.norm.weight), ensure_grad(m.norm.bias), M=B * npre,
+                          xmap=RowMap(npre, N, 0), dxmap=RowMap(npre, N, 0))
+        ctx.saved = None
+        return g, None, None
+
+
+# ----------------------------------------------------------------------------------------------- the model
+class VisionTransformer(nn.Module):
+    def __init__(self, embed_dim=192, depth=12, num_heads=3, num_classes=1000, distilled=False, drop_path_rate=0.0,
+                 img_size=224, patch_size=16, in_chans=3, mlp_ratio=4.0):
+        super().__init__()
+        self.embed_dim, self.num_classes, self.distilled = embed_dim, num_classes, distilled
+        self.num_prefix_tokens = 2 if distilled else 1
+        self.distilled_training = False
+        self.patch_embed = PatchEmbed(img_size, patch_size, in_chans, embed_dim)
+        self.num_tokens = self.patch_embed.num_patches + self.num_prefix_tokens
+        self.cls_token = nn.Parameter(torch.zeros(1, 1, embed_dim))
+        if distilled:
+            self.dist_token = nn.Parameter(torch.zeros(1, 1, embed_dim))
+        self.pos_embed = nn.Parameter(torch.zeros(1, self.num_tokens, embed_dim))
+        dpr = [v.item() for v in torch.linspace(0, drop_path_rate, depth)]
+        self.blocks = nn.ModuleList([Block(embed_dim, num_heads, mlp_ratio, dpr[i]) for i in range(depth)])
+        self.norm = LayerNormP(embed_dim)
+        self.head = Linear(embed_dim, num_classes)
+        if distilled:
+            self.head_dist = Linear(embed_dim, num_classes)
+        _trunc_normal_(self.pos_embed, std=.02)
+        nn.init.normal_(self.cls_token, std=1e-6)
+        if distilled:
+            _trunc_normal_(self.dist_token, std=.02)
+        self._shadow = Shadow()
+        self._keep: Optional[List[torch.Tensor]] = None
+
+    # -- timm surface
+    def no_weight_decay(self):
+        return {"pos_embed", "cls_token", "dist_token"}
+
+    def set_distilled_training(self, enable=True):
+        self.distilled_training = enable
+
+    def set_droppath_keep(self, keep: Optional[Sequence[torch.Tensor]]):
+        """Inject the Bernoulli draws of DropPath (2 per block, [B] 0/1) instead of sampling them (parity tests)."""
+        self._keep = None if keep is None else [k.to(F32) for k in keep]
+
+    def _apply(self, fn, *a, **k):
+        self._shadow.clear()
+        return super()._apply(fn, *a, **k)
+
+    # -- pieces
+    def _droppath_scales(self, B, device):
+        if not self.training:
+            return [None] * (2 * len(self.blocks))
+        probs = [blk.drop_prob for blk in self.blocks for _ in range(2)]
+        if self._keep is not None:
+            return [None if p == 0.0 else (self._keep[i].to(device) / (1.0 - p)).contiguous() for i, p in enumerate(probs)]
+        if max(probs) == 0.0:
+            return [None] * len(probs)
+        keep_prob = 1.0 - torch.tensor(probs, device=device, dtype=F32)[:, None]
+        scale = (torch.rand(len(probs), B, device=device) < keep_prob).to(F32) / keep_prob
+        return [None if p == 0.0 else scale[i] for i, p in enumerate(probs)]
+
+    def _embed(self, img):
+        if not img.is_cuda:
+            raise RuntimeError("deltakd_amd.vit: input must live on an MI355X device (no CPU path)")
+        img = img.contiguous().float()
+        B = img.shape[0]
+        N, D, npre = self.num_tokens, self.embed_dim, self.num_prefix_tokens
+        P = N - npre
+        patches = ops.im2col_patches(img, self.patch_embed.patch_size)
+        x = torch.empty(B * N, D, device=img.device, dtype=F32)
+        pos = self.pos_embed.view(N, D)
+        ops.gemm_nt(patches, self._shadow.get(self.patch_embed.proj.weight), out=x, bias=self.patch_embed.proj.bias,
+                    cmap=strip_map(N, npre), resid=pos, rmap=RowMap(P, 0, npre))
+        tok = self.cls_token.view(1, D) if npre == 1 else torch.cat([self.cls_token.view(1, D), self.dist_token.view(1, D)], 0)
+        ops.prefix_tokens_fwd(x, tok.detach().contiguous(), pos, B, N, D, npre)
+        return x, patches
+
+    def forward_tokens(self, img, tap_layers: Optional[Sequence[int]] = None):
+        """-> (x f32 [B*N, D] after the last block, taps: list (len depth) of bf16 [B, N, D] or None)."""
+        B = img.shape[0]
+        N = self.num_tokens
+        depth = len(self.blocks)
+        want = set(range(depth)) if tap_layers is None else {i % depth for i in tap_layers}
+        taps: List[Optional[torch.Tensor]] = [None] * depth
+        grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+        scales = self._droppath_scales(B, img.device)
+        if grad:
+            x = _EmbedFn.apply(self.pos_embed, self, img)
+            for i in range(depth):
+                x, tap = _BlockFn.apply(x, self, i, B, N, scales[2 * i], scales[2 * i + 1], i in want)
+                if i in want:
+                    taps[i] = tap.view(B, N, self.embed_dim)
+        else:
+            x, _ = self._embed(img)
+            for i, blk in enumerate(self.blocks):
+                x, tap, _ = _block_forward(x, B, N, blk, self._shadow, scales[2 * i], scales[2 * i + 1], False, i in want, True)
+                if tap is not None:
+                    taps[i] = tap.view(B, N, self.embed_dim)
+        return x, taps
+
+    def forward_head(self, x, B):
+        if torch.is_grad_enabled() and x.requires_grad:
+            outs = _HeadFn.apply(x, self, B)
+        else:
+            N, D, npre = self.num_tokens, self.embed_dim, self.num_prefix_tokens
+            y, _, _ = ops.layernorm_fwd(x, self.norm.weight, self.norm.bias, M=B * npre, xmap=RowMap(npre, N, 0), save_stats=False)
+            heads = [self.head] + ([self.head_dist] if self.distilled else [])
+            outs = tuple(ops.gemm_nt(y, self._shadow.get(hd.weight), M=B, amap=RowMap(1, npre, t), bias=hd.bias, out_f32=True)
+                         for t, hd in enumerate(heads))
+        if not self.distilled:
+            return outs[0]
+        if self.distilled_training and self.training:
+            return outs[0], outs[1]
+        return (outs[0] + outs[1]) / 2
+
+    def forward_with_taps(self, img, tap_layers=None):
+        x, taps = self.forward_tokens(img, tap_layers)
+        return self.forward_head(x, img.shape[0]), taps
+
+    def forward(self, img):
+        x, _ = self.forward_tokens(img, tap_layers=())
+        return self.forward_head(x, img.shape[0])
+
+
+def create_model(name, pretrained=False, drop_path_rate=0.0, num_classes=1000, **kw):
+    """Counterpart of ``timm.create_model`` for the names the reference scripts use (exp/*.sh).
+
+    ``pretrained=True`` cannot fetch weights (no network on the MI355X boxes): pass ``checkpoint_path=<local file>`` to load a
+    timm state dict, otherwise the (frozen) teacher keeps its seeded random init -- the throughput / parity runs use that.
+    """
+    ckpt = kw.pop("checkpoint_path", None)
+    if name not in REGISTRY:
+        raise ValueError(f"unknown model {name!r}; known: {sorted(REGISTRY)}")
+    D, depth, H, dist = REGISTRY[name]
+    model = VisionTransformer(D, depth, H, num_classes, dist, drop_path_rate, **kw)
+    if ckpt:
+        sd = torch.load(ckpt, map_location="cpu", weights_only=True)
+        sd = sd.get("model", sd)
+        own = model.state_dict()
+        sd = {k: v for k, v in sd.items() if k in own and v.shape == own[k].shape}   # head re-initialised on class mismatch
+        model.load_state_dict(sd, strict=False)
+    return model

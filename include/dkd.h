@@ -103,9 +103,9 @@ int dkd_im2col_patches(const float* img, void* patches, int32_t B, int32_t C, in
 int dkd_prefix_tokens_fwd(float* x, const float* tok, const float* pos, int32_t B, int32_t N, int32_t D, int32_t npre, void* stream);
 /* dtok[t,:] += sum_b dx[b,t,:] (t < npre);  dpos[t,:] += sum_b dx[b,t,:] (all t). */
 int dkd_embed_bwd(const float* dx, float* dtok, float* dpos, int32_t B, int32_t N, int32_t D, int32_t npre, void* stream);
-/* y bf16 [M, D] = (rowscale ? rowscale[m / rows_per_sample] : 1) * x[xmap(m)] (+ add[m] if add) ; x, add f32. */
+/* y bf16 [M, D] = (rowscale ? rowscale[m / rows_per_sample] : 1) * x[xmap(m)] (+ add[m] if add) ; x f32, add f32|bf16. */
 int dkd_scale_cast_bf16(const float* x, int32_t ldx, DkdRowMap xmap, const float* rowscale, int32_t rows_per_sample,
-                        const float* add, int32_t ldadd, void* y, int32_t ldy, int32_t M, int32_t D, void* stream);
+                        const void* add, int32_t add_is_f32, int32_t ldadd, void* y, int32_t ldy, int32_t M, int32_t D, void* stream);
 /* f32 -> bf16 flat cast; optionally also the transpose of a [rows, cols] matrix (w_t may be NULL). */
 int dkd_cast_weight(const float* w, void* w_bf16, void* w_t_bf16, int32_t rows, int32_t cols, void* stream);
 /* out[n] += sum_m x[amap(m), n]; x bf16 (or f32 if x_is_f32) [M, N] : bias gradients. */

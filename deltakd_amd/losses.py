@@ -123,35 +123,94 @@ class _AlignMseFn(torch.autograd.Function):
         return dtap.view(B, N, Ds), None, None, None, None, None, None
 
 
-@torch.no_grad()
+class LowRankTargets:
+    """U_k S_k of the [B*P, Dt] teacher matrices (model/loss.py:318-324), computed as T V_k without factorising T.
+
+    Gram matrices G_l = T_l^T T_l come from the split-M MFMA wgrad kernel; their leading invariant subspace is found by
+    block subspace iteration (block b = min(Dt, 128) > rank: oversampling), all layers batched:
+        Y = G V;  V = orth(Y)   (orth: column scaling + Gram + LDS-resident Jacobi eigensolver, no Cholesky breakdown)
+    followed by one Rayleigh-Ritz step (b x b Jacobi) that orders the Ritz vectors by singular value, so column j equals
+    the j-th right singular vector up to sign (the sign LAPACK picks is arbitrary too: SURVEY.md section 0 item 9).
+    The converged basis is kept and warm-starts the next call: the teacher is frozen, so consecutive batches share their
+    principal subspace and ``warm_iters`` refinement steps per call keep it converged.  Dt <= 128 is solved exactly.
+    """
+
+    def __init__(self, block=128, cold_iters=16, warm_iters=2, sweeps=10):
+        self.block, self.cold_iters, self.warm_iters, self.sweeps = block, cold_iters, warm_iters, sweeps
+        self.basis = None
+
+    def _orth(self, Y):
+        Yn = Y / Y.norm(dim=1, keepdim=True).clamp_min(1e-30)
+        S = torch.bmm(Yn.transpose(1, 2), Yn)
+        e, Q = ops.jacobi_eigh(0.5 * (S + S.transpose(1, 2)), self.sweeps)
+        e = torch.maximum(e, e[:, :1] * 1e-12)
+        return torch.bmm(Yn, Q * torch.rsqrt(e)[:, None, :])
+
+    @torch.no_grad()
+    def right_vectors(self, G, rank):
+        """G f32 [L, Dt, Dt] symmetric PSD -> V f32 [L, Dt, rank], columns by descending eigenvalue."""
+        L, Dt, _ = G.shape
+        G = 0.5 * (G + G.transpose(1, 2))
+        if Dt <= 128:
+            _, W = ops.jacobi_eigh(G, max(self.sweeps, 12))
+            return W[:, :, :rank]
+        b = min(self.block, 128)
+        if rank > b:
+            raise ValueError(f"lrkd rank {rank} exceeds the subspace block {b}")
+        if self.basis is None or self.basis.shape != (L, Dt, b):
+            gen = torch.Generator(device=G.device).manual_seed(1234)
+            V = self._orth(torch.randn(L, Dt, b, device=G.device, dtype=F32, generator=gen))
+            iters = self.cold_iters
+        else:
+            V, iters = self.basis, self.warm_iters
+        for _ in range(iters):
+            V = self._orth(torch.bmm(G, V))
+        V = self._orth(V)                                     # second pass: orthonormal to fp32 roundoff
+        H = torch.bmm(V.transpose(1, 2), torch.bmm(G, V))
+        _, W = ops.jacobi_eigh(0.5 * (H + H.transpose(1, 2)), self.sweeps)
+        V = torch.bmm(V, W)                                   # Ritz vectors, descending
+        self.basis = V
+        return V[:, :, :rank]
+
+    @torch.no_grad()
+    def __call__(self, taps, npre, rank):
+        """taps: list of bf16 [B, N, Dt] -> list of f32 [B*P, rank]."""
+        B, N, Dt = taps[0].shape
+        P = N - npre
+        smap = strip_map(N, npre)
+        Ts = [t.reshape(B * N, Dt) for t in taps]
+        G = torch.zeros(len(Ts), Dt, Dt, device=Ts[0].device, dtype=F32)
+        for i, T in enumerate(Ts):
+            ops.gemm_tn(T, T, G[i], M=B * P, amap=smap, bmap=smap)
+        V = self.right_vectors(G, rank)
+        out = []
+        for i, T in enumerate(Ts):
+            Vt = V[i].t().contiguous()                        # [rank, Dt]
+            hi = Vt.to(BF16)
+            lo = (Vt - hi.float()).to(BF16)                   # bf16 hi/lo split keeps ~16 bits of V through the bf16 MFMA
+            A = ops.gemm_nt(T, hi, M=B * P, amap=smap, out_f32=True)
+            ops.gemm_nt(T, lo, out=A, M=B * P, amap=smap, accumulate=True)
+            out.append(A)
+        return out
+
+
 def lrkd_targets(t_tap, npre, rank):
-    """U_k S_k of the [B*P, Dt] teacher matrix (model/loss.py:318-324) as T V_k; t_tap bf16 [B, N, Dt] -> f32 [B*P, rank]."""
-    B, N, Dt = t_tap.shape
-    P = N - npre
-    T = t_tap.reshape(B * N, Dt)
-    smap = strip_map(N, npre)
-    G = torch.zeros(Dt, Dt, device=T.device, dtype=F32)
-    ops.gemm_tn(T, T, G, M=B * P, amap=smap, bmap=smap)
-    G = 0.5 * (G + G.t())
-    _, evecs = torch.linalg.eigh(G)                       # ascending eigenvalues; [Dt, Dt] glue (hipSOLVER)
-    Vt = evecs[:, -rank:].flip(1).t().contiguous()        # [rank, Dt], descending singular values
-    hi = Vt.to(BF16)
-    lo = (Vt - hi.float()).to(BF16)                       # bf16 hi/lo split keeps ~16 bits of V through the bf16 MFMA
-    A = ops.gemm_nt(T, hi, M=B * P, amap=smap, out_f32=True)
-    ops.gemm_nt(T, lo, out=A, M=B * P, amap=smap, accumulate=True)
-    return A
+    """Single-matrix convenience wrapper (cold start): bf16 [B, N, Dt] -> f32 [B*P, rank]."""
+    return LowRankTargets()([t_tap], npre, rank)[0]
 
 
 def lrkd_loss(teacher_features, student_features, rank=10, alpha=0.1, beta=0.1, gamma=0.1, *, student_model=None, npre_s=1,
-              npre_t=2, targets=None):
+              npre_t=2, targets=None, solver=None):
     """model/loss.py:314-330.  ``student_features`` are the raw block taps (bf16 [B, N, Ds]); the align Linear of
     model/loss.py:88-92 is fused into the term, so ``student_model`` (owner of ``align``) is required."""
     if student_model is None:
         raise ValueError("lrkd_loss needs student_model= (the align projections are fused into the loss kernels)")
     sm = _unwrap(student_model)
     total = None
+    if targets is None:
+        targets = (solver or LowRankTargets())(list(teacher_features), npre_t, rank)
     for i, w in enumerate((alpha, beta, gamma)):
-        tgt = targets[i] if targets is not None else lrkd_targets(teacher_features[i], npre_t, rank)
+        tgt = targets[i]
         term = _AlignMseFn.apply(student_features[i], sm.align[i], sm._shadow, tgt, IDENT, float(w), npre_s)
         total = term if total is None else total + term
     return total
@@ -168,7 +227,7 @@ class DistillationLoss(nn.Module):
         self.tau = tau
         self.teacher_stream = teacher_stream
         self.injected = {}          # parity tests inject random draws / precomputed targets here
-        self.last_parts = None
+        self.lowrank = LowRankTargets()
 
     # which teacher block taps each branch consumes (model/loss.py:95-99,117-121,193,428)
     _TAPS = {"lrkd": (0, 1, 11), "diffkd": (0, 1, -1), "wasskd": (0, 1, 2), "mgd": (-1,), "vitkd": (0, 1, -1),
@@ -182,7 +241,11 @@ class DistillationLoss(nn.Module):
         fwt = getattr(_unwrap(t), "forward_with_taps", None)
         if fwt is None:
             raise RuntimeError("teacher model has no forward_with_taps(); build it with deltakd_amd.vit.create_model")
-        return fwt(inputs, self._TAPS.get(kind))
+        logits, taps = fwt(inputs, self._TAPS.get(kind))
+        if kind == "lrkd" and "lrkd_targets" not in self.injected:      # no-grad teacher-side work stays on the teacher stream
+            pt = getattr(_unwrap(t), "num_prefix_tokens", 2)
+            self._lrkd_tgt = self.lowrank([taps[0], taps[1], taps[11]], pt, self._lrkd_rank)
+        return logits, taps
 
     def _base(self, outputs, labels, w_base, kd_mode=0, z_kd=None, z_t=None, w_kd=0.0):
         crit = self.base_criterion
@@ -209,6 +272,8 @@ class DistillationLoss(nn.Module):
         if kind not in ("soft", "hard", "lrkd", "mgd", "wasskd", "diffkd"):
             raise ValueError(f"Invalid distillation type: {self.distillation_type}")
 
+        self._lrkd_rank = getattr(args, "lrkd_rank", 0)
+        self._lrkd_tgt = None
         if self.teacher_stream is not None:
             self.teacher_stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self.teacher_stream):
@@ -229,7 +294,8 @@ class DistillationLoss(nn.Module):
             sel_s = [student_features[0], student_features[1], student_features[-1]]
             sel_t = [t_taps[0], t_taps[1], t_taps[11]]
             d = lrkd_loss(sel_t, sel_s, args.lrkd_rank, a * args.lrkd_alpha, a * args.lrkd_beta, a * args.lrkd_gamma,
-                          student_model=sm, npre_s=ps, npre_t=pt, targets=self.injected.get("lrkd_targets"))
+                          student_model=sm, npre_s=ps, npre_t=pt, targets=self.injected.get("lrkd_targets", self._lrkd_tgt),
+                          solver=self.lowrank)
             return base + d
         from . import losses_ext
         if kind == "mgd":

@@ -238,3 +238,16 @@ def mask_select_bwd(dout, mask, dmask_token):
 def adamw_step(p, g, m, v, p_bf16, lr, beta1, beta2, eps, wd, step, grad_scale=1.0):
     check(lib().dkd_adamw_step(ptr(p), ptr(g), ptr(m), ptr(v), ptr(p_bf16), p.numel(), lr, beta1, beta2, eps, wd, step, grad_scale,
                                stream()), "adamw")
+
+
+def jacobi_eigh(A, sweeps=10):
+    """A f32 [batch, n, n] symmetric (n <= 128) -> (evals [batch, n] descending, evecs [batch, n, n], columns sorted alike)."""
+    assert A.dtype == F32 and A.dim() == 3 and A.shape[1] == A.shape[2]
+    A = A.contiguous()
+    bt, n, _ = A.shape
+    ev = torch.empty(bt, n, device=A.device, dtype=F32)
+    vec = torch.empty(bt, n, n, device=A.device, dtype=F32)
+    check(lib().dkd_jacobi_eigh(ptr(A), ptr(ev), ptr(vec), bt, n, sweeps, stream()), "jacobi_eigh")
+    ev, order = torch.sort(ev, dim=1, descending=True)
+    vec = torch.gather(vec, 2, order[:, None, :].expand(bt, n, n))
+    return ev, vec

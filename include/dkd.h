@@ -137,6 +137,11 @@ int dkd_mask_select_bwd(const void* dout, const float* mask, void* dx, float* dm
 int dkd_sort_l1_loss(const void* s, int32_t s_is_f32, const void* t, int32_t t_is_f32, int32_t ldt, DkdRowMap tmap, float w,
                      float* loss, void* ds, int32_t ds_is_f32, int32_t B, int32_t P, int32_t D, void* stream);
 
+/* ---------------------------------------------------------------- small dense eigensolver (LRKD target, model/loss.py:321) */
+/* Batched cyclic Jacobi: A f32 [batch, n, n] symmetric, n <= 128 -> evals [batch, n] (unsorted), evecs [batch, n, n]
+ * (column j pairs with evals[j]).  One workgroup per matrix, LDS-resident; `sweeps` full sweeps (10 converges fp32). */
+int dkd_jacobi_eigh(const float* A, float* evals, float* evecs, int32_t batch, int32_t n, int32_t sweeps, void* stream);
+
 /* ---------------------------------------------------------------- optimizer ([3P] torch.optim.AdamW via timm create_optimizer) */
 /* One launch over a flat parameter segment; optionally refreshes the bf16 shadow copy used by the GEMMs. */
 int dkd_adamw_step(float* p, const float* g, float* m, float* v, void* p_bf16, int64_t n, float lr, float beta1, float beta2,

@@ -294,3 +294,42 @@ def test_errors_are_loud(ops):
         ops.gemm_nt(a, a)            # K not a multiple of 64
     with pytest.raises(RuntimeError):
         ops.gemm_nt(torch.zeros(4, 64, dtype=BF16), torch.zeros(4, 64, dtype=BF16))   # host tensors
+
+
+@pytest.mark.parametrize("n,batch", [(8, 2), (31, 3), (96, 3), (128, 2)])
+def test_jacobi_eigh(ops, n, batch):
+    x = rnd(batch, n, n, seed=90)
+    A = x @ x.transpose(1, 2) / n + torch.diag_embed(torch.linspace(0, 3, n, device=dev()).expand(batch, n))
+    ev, vec = ops.jacobi_eigh(A)
+    ref = torch.linalg.eigvalsh(A.double().cpu()).flip(1)
+    close(ev.cpu(), ref, 2e-6 * n, "eigenvalues")
+    recon = vec @ torch.diag_embed(ev) @ vec.transpose(1, 2)
+    close(recon, A, 2e-5, "V diag V^T")
+    eye = torch.eye(n, device=dev()).expand(batch, n, n)
+    close(vec.transpose(1, 2) @ vec, eye, 2e-5, "orthonormal")
+
+
+def test_lowrank_targets_vs_svd(ops):
+    """Dt = 768 (subspace iteration + Rayleigh-Ritz path): U_k S_k against torch.linalg.svd on the host, up to column sign.
+    Cold start, then a warm-started call on a different batch drawn from the same feature distribution."""
+    from deltakd_amd.losses import LowRankTargets
+    B, N, Dt, r = 16, 198, 768, 64
+    g = torch.Generator().manual_seed(7)
+    basis = torch.linalg.qr(torch.randn(Dt, Dt, generator=g))[0]
+    spec = torch.cat([torch.linspace(30, 6, 24), 5.0 * torch.exp(-torch.arange(Dt - 24) / 40.0) + 0.2])
+    solver = LowRankTargets()
+    for call in range(2):
+        t = (torch.randn(B * N, Dt, generator=g) * spec) @ basis.t()
+        tb = t.to(BF16).to(dev()).view(B, N, Dt)
+        got = solver([tb], 2, r)[0].cpu()
+        T = tb.float().cpu()[:, 2:].reshape(-1, Dt)
+        U, S, _ = torch.linalg.svd(T, full_matrices=False)
+        ref = U[:, :r] * S[:r]
+        sv = got.norm(dim=0)
+        assert (sv - S[:r]).abs().max().item() <= 2e-3 * S[0].item(), f"call {call}: singular values"
+        sign = torch.sign((got * ref).sum(0))
+        lead = 24                                       # well-separated part of the spectrum: vectors are well-conditioned
+        err = ((got[:, :lead] * sign[:lead]) - ref[:, :lead]).norm() / ref[:, :lead].norm()
+        assert err.item() < 2e-2, f"call {call}: leading columns rel err {err.item()}"
+        # whole rank-r approximation (sign- and rotation-invariant): ||T V_r|| captured energy
+        assert abs(got.norm().item() - ref.norm().item()) <= 2e-3 * ref.norm().item()

@@ -30,8 +30,3 @@ extern "C" int dkd_device_info(int device, int* cu_count, char* name, int name_l
   return DKD_OK;
 }
 
-extern "C" int dkd_sort_l1_loss(const void*, int32_t, const void*, int32_t, int32_t, DkdRowMap, float, float*, void*, int32_t, int32_t,
-                                int32_t, int32_t, void*) {
-  dkd_set_error("sort_l1_loss: not built yet");
-  return DKD_ERR_UNSUPPORTED;
-}

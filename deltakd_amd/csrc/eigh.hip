@@ -20,6 +20,7 @@ __global__ __launch_bounds__(1024) void jacobi_eigh_kernel(const float* __restri
   float* V = A + NMAX * LD;      // [ne][LD]
   float* cs = V + NMAX * LD;     // c[64], s[64]
   int* pq = (int*)(cs + 2 * (NMAX / 2));  // p[64], q[64]
+  int* rotated = pq + 2 * (NMAX / 2);     // rotations applied in the current sweep (convergence test)
   const int tid = threadIdx.x, nt = blockDim.x;
   const int ne = (n + 1) & ~1;   // even working size (a padded index gets a zero row/col and never rotates)
   const int half = ne >> 1;
@@ -31,6 +32,8 @@ __global__ __launch_bounds__(1024) void jacobi_eigh_kernel(const float* __restri
   }
   __syncthreads();
   for (int sw = 0; sw < sweeps; ++sw) {
+    if (tid == 0) *rotated = 0;
+    __syncthreads();
     for (int rd = 0; rd < ne - 1; ++rd) {
       // round-robin tournament: position 0 is fixed, the other ne-1 positions rotate by rd
       if (tid < half) {
@@ -40,7 +43,9 @@ __global__ __launch_bounds__(1024) void jacobi_eigh_kernel(const float* __restri
         const int p = a < b ? a : b, q = a < b ? b : a;
         const float app = A[p * LD + p], aqq = A[q * LD + q], apq = A[p * LD + q];
         float c = 1.f, s = 0.f;
-        if (fabsf(apq) > 1e-12f * sqrtf(fabsf(app * aqq)) && apq != 0.f) {
+        // threshold Jacobi: an off-diagonal below fp32 roundoff of sqrt(app aqq) cannot change either eigenvalue
+        if (fabsf(apq) > 6e-8f * sqrtf(fabsf(app * aqq)) && apq != 0.f) {
+          atomicOr(rotated, 1);
           const float tau = (aqq - app) / (2.f * apq);
           const float t = (tau >= 0.f ? 1.f : -1.f) / (fabsf(tau) + sqrtf(1.f + tau * tau));
           c = rsqrtf(1.f + t * t);
@@ -77,6 +82,8 @@ __global__ __launch_bounds__(1024) void jacobi_eigh_kernel(const float* __restri
       }
       __syncthreads();
     }
+    if (*rotated == 0) break;     // a full sweep without a rotation: converged (uniform across the workgroup)
+    __syncthreads();
   }
   for (int i = tid; i < n; i += nt) evals[(size_t)blockIdx.x * n + i] = A[i * LD + i];
   float* Vb = evecs + (size_t)blockIdx.x * n * n;
@@ -88,7 +95,7 @@ __global__ __launch_bounds__(1024) void jacobi_eigh_kernel(const float* __restri
 extern "C" int dkd_jacobi_eigh(const float* A, float* evals, float* evecs, int32_t batch, int32_t n, int32_t sweeps, void* stream) {
   DKD_CHECK_ARG(A && evals && evecs, "jacobi_eigh: null operand");
   DKD_CHECK_ARG(batch > 0 && n > 0 && n <= NMAX && sweeps > 0, "jacobi_eigh: need 0 < n <= %d (n=%d)", NMAX, n);
-  const int smem = (2 * NMAX * LD + 2 * (NMAX / 2)) * 4 + 2 * (NMAX / 2) * 4;
+  const int smem = (2 * NMAX * LD + 2 * (NMAX / 2)) * 4 + 2 * (NMAX / 2) * 4 + 16;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)jacobi_eigh_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, smem);

@@ -77,6 +77,14 @@ _SIGS = {
     "dkd_mask_select_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "dkd_sort_l1_loss": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, RowMap, C.c_float, C.c_void_p,
                                    C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "dkd_im2col3x3": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "dkd_col2im3x3": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "dkd_normalize_mse": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
+                                    C.c_int32, C.c_void_p]),
+    "dkd_diffkd_prepare": (C.c_int, [C.c_void_p, C.c_int32, RowMap, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
+                                     C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
+    "dkd_dropout_mse": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_int64,
+                                  C.c_void_p]),
     "dkd_jacobi_eigh": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "dkd_adamw_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float,
                                  C.c_float, C.c_float, C.c_float, C.c_int32, C.c_float, C.c_void_p]),

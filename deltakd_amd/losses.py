@@ -87,25 +87,24 @@ def _pad64(n):
     return (n + 63) // 64 * 64
 
 
-class _AlignMseFn(torch.autograd.Function):
-    """scale * mean(mask * (align(tap[:, npre:]) - target)^2): align GEMM + fused MSE/dMSE; backward = dgrad + wgrad GEMMs.
+class _AlignTermFn(torch.autograd.Function):
+    """One feature-distillation term on a student block tap: align Linear (MFMA GEMM on tap[:, npre:], prefix tokens
+    skipped through a row map) -> fused loss+gradient kernel chosen by ``loss_cb`` -> (backward) wgrad + dgrad GEMMs.
 
-    tap: bf16 [B, N, Ds] (student block tap);  target: f32|bf16 [B*P, Dt] rows through ``tmap``.
+    tap: bf16 [B, N, Ds].  ``loss_cb(s, loss, Kp)`` receives the aligned features s f32 [B*P, Dt], accumulates the term
+    into ``loss`` (f32 [1]) and returns d term / d s as bf16 [B*P, Kp] (Kp = Dt padded to the GEMM's K granule).
     """
 
     @staticmethod
-    def forward(ctx, tap, align: Linear, shadow, target, tmap, scale, npre):
+    def forward(ctx, tap, align: Linear, shadow, npre, loss_cb):
         B, N, Ds = tap.shape
         P = N - npre
         M, Dt = B * P, align.out_features
         tap2 = tap.reshape(B * N, Ds)
         s = ops.gemm_nt(tap2, shadow.get(align.weight), M=M, amap=strip_map(N, npre), bias=align.bias, out_f32=True)
         loss = torch.zeros(1, device=tap.device, dtype=F32)
-        if target.stride(-1) != 1:
-            target = target.contiguous()       # e.g. a column-major LAPACK result
         Kp = _pad64(Dt)
-        da = torch.zeros(M, Kp, device=tap.device, dtype=BF16) if Kp != Dt else torch.empty(M, Kp, device=tap.device, dtype=BF16)
-        ops.mse_loss(s, target, loss, scale / (M * Dt), M=M, tmap=tmap, grad_out=da)
+        da = loss_cb(s, loss, Kp)
         ctx.align, ctx.shadow, ctx.tap2, ctx.da, ctx.dims = align, shadow, tap2, da, (B, N, Ds, npre, M, Dt, Kp)
         return loss[0]
 
@@ -113,14 +112,31 @@ class _AlignMseFn(torch.autograd.Function):
     def backward(ctx, g):
         B, N, Ds, npre, M, Dt, Kp = ctx.dims
         align, da = ctx.align, ctx.da
-        da.mul_(g.to(BF16))
+        da.mul_(g.to(da.dtype))
         smap = strip_map(N, npre)
         ops.gemm_tn(da, ctx.tap2, ensure_grad(align.weight), M=M, N1=Dt, bmap=smap)
         ops.colsum(da, ensure_grad(align.bias), N=Dt)
         dtap = torch.zeros(B * N, Ds, device=da.device, dtype=BF16)
         ops.gemm_nt(da, ctx.shadow.get(align.weight, transposed=True, pad_k_to=Kp), out=dtap, cmap=smap)
         ctx.da = ctx.tap2 = None
-        return dtap.view(B, N, Ds), None, None, None, None, None, None
+        return dtap.view(B, N, Ds), None, None, None, None
+
+
+def _grad_buffer(M, D, Kp, device):
+    return torch.zeros(M, Kp, device=device, dtype=BF16) if Kp != D else torch.empty(M, Kp, device=device, dtype=BF16)
+
+
+def align_mse_term(tap, align, shadow, target, tmap, scale, npre, mask=None):
+    """scale * mean(mask * (align(tap[:, npre:]) - target)^2)   (model/loss.py:326)."""
+    if target.stride(-1) != 1:
+        target = target.contiguous()           # e.g. a column-major LAPACK result
+
+    def cb(s, loss, Kp):
+        M, D = s.shape
+        da = _grad_buffer(M, D, Kp, s.device)
+        ops.mse_loss(s, target, loss, scale / (M * D), M=M, tmap=tmap, mask=mask, grad_out=da)
+        return da
+    return _AlignTermFn.apply(tap, align, shadow, npre, cb)
 
 
 class LowRankTargets:
@@ -135,9 +151,21 @@ class LowRankTargets:
     principal subspace and ``warm_iters`` refinement steps per call keep it converged.  Dt <= 128 is solved exactly.
     """
 
-    def __init__(self, block=128, cold_iters=16, warm_iters=2, sweeps=10):
-        self.block, self.cold_iters, self.warm_iters, self.sweeps = block, cold_iters, warm_iters, sweeps
+    def __init__(self, block=96, cold_iters=16, warm_iters=1, sweeps=10, ns_iters=10):
+        self.block, self.cold_iters, self.warm_iters, self.sweeps, self.ns_iters = block, cold_iters, warm_iters, sweeps, ns_iters
         self.basis = None
+
+    def _orth_warm(self, Y):
+        """Newton-Schulz orthonormalisation (GEMMs only): for a warm-started basis the columns of G V are already nearly
+        orthogonal, so X <- X (3 I - X^T X) / 2 converges quadratically; X is first scaled so that sigma_max <= 1
+        (||X^T X||_1 bounds sigma_max^2), which makes the iteration safe for any input."""
+        X = Y / Y.norm(dim=1, keepdim=True).clamp_min(1e-30)
+        S = torch.bmm(X.transpose(1, 2), X)
+        X = X * torch.rsqrt(S.abs().sum(dim=1).amax(dim=1))[:, None, None]
+        for _ in range(self.ns_iters):
+            S = torch.bmm(X.transpose(1, 2), X)
+            X = torch.baddbmm(X, X, S, beta=1.5, alpha=-0.5)
+        return X
 
     def _orth(self, Y):
         Yn = Y / Y.norm(dim=1, keepdim=True).clamp_min(1e-30)
@@ -160,12 +188,13 @@ class LowRankTargets:
         if self.basis is None or self.basis.shape != (L, Dt, b):
             gen = torch.Generator(device=G.device).manual_seed(1234)
             V = self._orth(torch.randn(L, Dt, b, device=G.device, dtype=F32, generator=gen))
-            iters = self.cold_iters
+            for _ in range(self.cold_iters):
+                V = self._orth(torch.bmm(G, V))
+            V = self._orth(V)                                 # second pass: orthonormal to fp32 roundoff
         else:
-            V, iters = self.basis, self.warm_iters
-        for _ in range(iters):
-            V = self._orth(torch.bmm(G, V))
-        V = self._orth(V)                                     # second pass: orthonormal to fp32 roundoff
+            V = self.basis
+            for _ in range(self.warm_iters):
+                V = self._orth_warm(torch.bmm(G, V))
         H = torch.bmm(V.transpose(1, 2), torch.bmm(G, V))
         _, W = ops.jacobi_eigh(0.5 * (H + H.transpose(1, 2)), self.sweeps)
         V = torch.bmm(V, W)                                   # Ritz vectors, descending
@@ -211,7 +240,7 @@ def lrkd_loss(teacher_features, student_features, rank=10, alpha=0.1, beta=0.1, 
         targets = (solver or LowRankTargets())(list(teacher_features), npre_t, rank)
     for i, w in enumerate((alpha, beta, gamma)):
         tgt = targets[i]
-        term = _AlignMseFn.apply(student_features[i], sm.align[i], sm._shadow, tgt, IDENT, float(w), npre_s)
+        term = align_mse_term(student_features[i], sm.align[i], sm._shadow, tgt, IDENT, float(w), npre_s)
         total = term if total is None else total + term
     return total
 

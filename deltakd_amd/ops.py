@@ -251,3 +251,59 @@ def jacobi_eigh(A, sweeps=10):
     ev, order = torch.sort(ev, dim=1, descending=True)
     vec = torch.gather(vec, 2, order[:, None, :].expand(bt, n, n))
     return ev, vec
+
+
+def im2col3x3(x, B, hw):
+    """x bf16 [B*hw*hw, C] (token grid) -> cols bf16 [B*hw*hw, 9*C]."""
+    assert x.dtype == BF16 and x.is_contiguous()
+    Cc = x.shape[1]
+    cols = torch.empty(x.shape[0], 9 * Cc, device=x.device, dtype=BF16)
+    check(lib().dkd_im2col3x3(ptr(x), ptr(cols), B, hw, Cc, stream()), "im2col3x3")
+    return cols
+
+
+def col2im3x3(dcols, B, hw, relu_gate=None):
+    assert dcols.dtype == BF16 and dcols.is_contiguous()
+    Cc = dcols.shape[1] // 9
+    dx = torch.empty(dcols.shape[0], Cc, device=dcols.device, dtype=BF16)
+    check(lib().dkd_col2im3x3(ptr(dcols), ptr(relu_gate), ptr(dx), B, hw, Cc, stream()), "col2im3x3")
+    return dx
+
+
+def sort_l1_loss(s, t, loss, w, *, B, P, tmap=IDENT, grad_f32=False):
+    """loss[0] += w * sum |sort_tokens(s) - sort_tokens(t)|; returns d loss / d s (same layout as s: [B*P, D])."""
+    D = s.shape[1]
+    assert s.is_contiguous() and s.shape[0] == B * P and t.stride(1) == 1
+    ds = torch.empty(B * P, D, device=s.device, dtype=F32 if grad_f32 else BF16)
+    check(lib().dkd_sort_l1_loss(ptr(s), _is_f32(s), ptr(t), _is_f32(t), t.stride(0), tmap, w, ptr(loss), ptr(ds), int(grad_f32), B, P, D,
+                                 stream()), "sort_l1_loss")
+    return ds
+
+
+def normalize_mse(s, t_hat, loss, w_over_denom, w_scalar=None, ld_grad=None):
+    assert s.dtype == F32 and s.is_contiguous() and t_hat.dtype == BF16 and t_hat.is_contiguous()
+    M, D = s.shape
+    ld = ld_grad or D
+    ds = torch.empty(M, ld, device=s.device, dtype=BF16) if ld == D else torch.zeros(M, ld, device=s.device, dtype=BF16)
+    check(lib().dkd_normalize_mse(ptr(s), ptr(t_hat), ptr(w_scalar), w_over_denom, ptr(loss), ptr(ds), ld, M, D, stream()), "normalize_mse")
+    return ds
+
+
+def diffkd_prepare(t, noise, sigma, temb, *, M, rows_per_sample, tmap=IDENT):
+    """-> (t_hat bf16 [M, D], nz f32 [M, D], x_in bf16 [M, D])."""
+    D = t.shape[1]
+    assert t.dtype == BF16 and noise.dtype == F32 and noise.is_contiguous() and temb.is_contiguous() and sigma.dtype == F32
+    t_hat = torch.empty(M, D, device=t.device, dtype=BF16)
+    nz = torch.empty(M, D, device=t.device, dtype=F32)
+    x_in = torch.empty(M, D, device=t.device, dtype=BF16)
+    check(lib().dkd_diffkd_prepare(ptr(t), t.stride(0), tmap, ptr(noise), ptr(sigma), ptr(temb), rows_per_sample, ptr(t_hat), ptr(nz),
+                                   ptr(x_in), M, D, stream()), "diffkd_prepare")
+    return t_hat, nz, x_in
+
+
+def dropout_mse(a, t, keep, keep_scale, loss, w_over_denom):
+    """loss[0] += w * sum (a*keep*scale - t)^2 -> gradient w.r.t. a (bf16, same shape)."""
+    assert a.dtype == F32 and t.dtype == F32 and a.is_contiguous() and t.is_contiguous()
+    da = torch.empty(a.shape, device=a.device, dtype=BF16)
+    check(lib().dkd_dropout_mse(ptr(a), ptr(t), ptr(keep), keep_scale, w_over_denom, ptr(loss), ptr(da), a.numel(), stream()), "dropout_mse")
+    return da

@@ -73,16 +73,20 @@ class Shadow:
         if bf16_fresh:
             self.bound_generation = self.generation
 
-    def get(self, p: torch.Tensor, transposed=False, pad_k_to=0):
-        key = (id(p), transposed, pad_k_to)
+    def get(self, p: torch.Tensor, transposed=False, pad_k_to=0, conv3x3=False):
+        """conv3x3: p is a [out, cin, 3, 3] conv weight, served as [out, (ky, kx, cin)] to match ops.im2col3x3's K order."""
+        key = (id(p), transposed, pad_k_to, conv3x3)
         slot = self._slots.get(key)
         stamp = (self.generation, p._version, p.data_ptr())
         if slot is not None and slot[0] == stamp:
             return slot[1]
-        w2 = p.detach().reshape(p.shape[0], -1)
+        if conv3x3:
+            w2 = p.detach().permute(0, 2, 3, 1).reshape(p.shape[0], -1).contiguous()
+        else:
+            w2 = p.detach().reshape(p.shape[0], -1)
         rows, cols = w2.shape
         if not transposed:
-            bound = self._bound.get(id(p))
+            bound = None if conv3x3 else self._bound.get(id(p))
             if bound is not None and self.bound_generation == self.generation:
                 buf = bound.view(rows, cols)                      # already refreshed by the AdamW kernel
             else:

@@ -137,6 +137,22 @@ int dkd_mask_select_bwd(const void* dout, const float* mask, void* dx, float* dm
 int dkd_sort_l1_loss(const void* s, int32_t s_is_f32, const void* t, int32_t t_is_f32, int32_t ldt, DkdRowMap tmap, float w,
                      float* loss, void* ds, int32_t ds_is_f32, int32_t B, int32_t P, int32_t D, void* stream);
 
+/* MGD generation block (model/models.py:148-151): Conv3x3(pad 1) on the hw x hw token grid as gather + dkd_gemm_nt.
+ * x bf16 [B, hw*hw, C] -> cols bf16 [B*hw*hw, 9*C] with k = (ky*3+kx)*C + c (conv weight permuted to [out, ky, kx, c]). */
+int dkd_im2col3x3(const void* x, void* cols, int32_t B, int32_t hw, int32_t C, void* stream);
+/* dx bf16 [B, hw*hw, C] = scatter-free transpose of im2col3x3 applied to dcols; relu_gate (bf16, optional): dx *= gate > 0. */
+int dkd_col2im3x3(const void* dcols, const void* relu_gate, void* dx, int32_t B, int32_t hw, int32_t C, void* stream);
+/* DiffKD (model/loss.py:138-149): loss += w_scalar[0] * w_over_denom * sum (s/|s| - t_hat)^2, ds (bf16) = gradient w.r.t. s.
+ * s f32 [M, D], t_hat bf16 [M, D] (already normalised), w_scalar device f32 (mean of the noise-aware weights) or NULL. */
+int dkd_normalize_mse(const float* s, const void* t_hat, const float* w_scalar, float w_over_denom, float* loss, void* ds,
+                      int32_t ldds, int32_t M, int32_t D, void* stream);
+/* t_hat = t/|t| (bf16), nz = noise * sigma[b] (f32), x_in = t_hat + nz + t_emb[b] (bf16); t bf16 rows through tmap. */
+int dkd_diffkd_prepare(const void* t, int32_t ldt, DkdRowMap tmap, const float* noise, const float* sigma, const float* temb,
+                       int32_t rows_per_sample, void* t_hat, float* nz, void* x_in, int32_t M, int32_t D, void* stream);
+/* loss += w * sum (a * keep * keep_scale - t)^2, da (bf16) its gradient: Dropout(0.1) folded into the noise-prediction MSE. */
+int dkd_dropout_mse(const float* a, const float* t, const float* keep, float keep_scale, float w_over_denom, float* loss, void* da,
+                    int64_t n, void* stream);
+
 /* ---------------------------------------------------------------- small dense eigensolver (LRKD target, model/loss.py:321) */
 /* Batched cyclic Jacobi: A f32 [batch, n, n] symmetric, n <= 128 -> evals [batch, n] (unsorted), evecs [batch, n, n]
  * (column j pairs with evals[j]).  One workgroup per matrix, LDS-resident; `sweeps` full sweeps (10 converges fp32). */

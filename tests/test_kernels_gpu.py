@@ -318,7 +318,7 @@ def test_lowrank_targets_vs_svd(ops):
     basis = torch.linalg.qr(torch.randn(Dt, Dt, generator=g))[0]
     spec = torch.cat([torch.linspace(30, 6, 24), 5.0 * torch.exp(-torch.arange(Dt - 24) / 40.0) + 0.2])
     solver = LowRankTargets()
-    for call in range(2):
+    for call in range(5):
         t = (torch.randn(B * N, Dt, generator=g) * spec) @ basis.t()
         tb = t.to(BF16).to(dev()).view(B, N, Dt)
         got = solver([tb], 2, r)[0].cpu()
@@ -333,3 +333,82 @@ def test_lowrank_targets_vs_svd(ops):
         assert err.item() < 2e-2, f"call {call}: leading columns rel err {err.item()}"
         # whole rank-r approximation (sign- and rotation-invariant): ||T V_r|| captured energy
         assert abs(got.norm().item() - ref.norm().item()) <= 2e-3 * ref.norm().item()
+
+
+def test_conv3x3_as_gather_gemm(ops):
+    """im2col3x3 + gemm_nt == Conv2d(C, C, 3, padding=1) on the token grid; col2im3x3 == its input gradient."""
+    import torch.nn.functional as F
+    B, hw, C = 3, 4, 64
+    x = rnd(B * hw * hw, C, seed=100).to(BF16)
+    w = rnd(C, C, 3, 3, scale=0.1, seed=101)
+    bias = rnd(C, seed=102)
+    wp = w.permute(0, 2, 3, 1).reshape(C, 9 * C).contiguous().to(BF16)
+    cols = ops.im2col3x3(x, B, hw)
+    y = ops.gemm_nt(cols, wp, bias=bias, out_f32=True)
+    xi = x.float().view(B, hw, hw, C).permute(0, 3, 1, 2).requires_grad_(True)
+    ref = F.conv2d(xi, w.to(BF16).float(), bias, padding=1)
+    close(y, ref.permute(0, 2, 3, 1).reshape(-1, C), 1e-4 * 24, "conv fwd")
+    dy = rnd(B * hw * hw, C, seed=103).to(BF16)
+    ref.backward(dy.float().view(B, hw, hw, C).permute(0, 3, 1, 2))
+    dcols = ops.gemm_nt(dy, wp.t().contiguous())
+    gate = rnd(B * hw * hw, C, seed=104).to(BF16)
+    dx = ops.col2im3x3(dcols, B, hw)
+    close(dx, xi.grad.permute(0, 2, 3, 1).reshape(-1, C), 2e-2, "conv dgrad")
+    dxg = ops.col2im3x3(dcols, B, hw, relu_gate=gate)
+    close(dxg, xi.grad.permute(0, 2, 3, 1).reshape(-1, C) * (gate.float() > 0), 2e-2, "conv dgrad relu")
+
+
+@pytest.mark.parametrize("B,P,D", [(2, 16, 128), (3, 196, 192), (2, 49, 100)])
+def test_sort_l1(ops, B, P, D):
+    from deltakd_amd.ffi import strip_map
+    N = P + 2
+    s = rnd(B * P, D, seed=110)
+    t = rnd(B * N, D, seed=111).to(BF16)
+    w = 5.0 / (3 * B * P * D)
+    loss = torch.zeros(1, device=dev())
+    ds = ops.sort_l1_loss(s, t, loss, w, B=B, P=P, tmap=strip_map(N, 2), grad_f32=True)
+    sr = s.view(B, P, D).clone().requires_grad_(True)
+    tt = t.float().view(B, N, D)[:, 2:]
+    ref = (5.0 / 3) * (torch.sort(sr, 1)[0] - torch.sort(tt, 1)[0]).abs().mean()
+    ref.backward()
+    close(loss, ref.detach(), 1e-5, "sort-l1 loss")
+    close(ds, sr.grad.reshape(B * P, D), 1e-5, "sort-l1 grad")
+
+
+def test_diffkd_kernels(ops):
+    from deltakd_amd.ffi import strip_map
+    B, P, D = 3, 16, 128
+    N = P + 2
+    M = B * P
+    t = rnd(B * N, D, seed=120).to(BF16)
+    noise = rnd(M, D, seed=121)
+    sigma = torch.tensor([0.0, 0.1852, 1.195], device=dev())
+    temb = rnd(B, D, seed=122)
+    t_hat, nz, x_in = ops.diffkd_prepare(t, noise, sigma, temb, M=M, rows_per_sample=P, tmap=strip_map(N, 2))
+    tt = t.float().view(B, N, D)[:, 2:]
+    th = tt / tt.norm(dim=-1, keepdim=True)
+    nzr = noise.view(B, P, D) * sigma.view(-1, 1, 1)
+    close(t_hat, th.reshape(M, D), 5e-3, "t_hat")
+    close(nz, nzr.reshape(M, D), 1e-6, "nz")
+    close(x_in, (th + nzr + temb[:, None]).reshape(M, D), 5e-3, "x_in")
+    # normalize + mse
+    s = rnd(M, D, scale=3.0, seed=123)
+    wsc = torch.tensor([1234.5], device=dev())
+    wod = 2e-5 / (M * D)
+    loss = torch.zeros(1, device=dev())
+    ds = ops.normalize_mse(s, t_hat, loss, wod, w_scalar=wsc)
+    sr = s.clone().requires_grad_(True)
+    ref = 1234.5 * 2e-5 * torch.nn.functional.mse_loss(sr / sr.norm(dim=-1, keepdim=True), t_hat.float())
+    ref.backward()
+    close(loss, ref.detach(), 1e-5, "normalize mse")
+    close(ds, sr.grad, 1e-2, "normalize mse grad (bf16)")
+    # dropout folded into mse
+    a = rnd(M, D, seed=124)
+    keep = (rnd(M, D, seed=125) > -1.0).float()
+    loss2 = torch.zeros(1, device=dev())
+    da = ops.dropout_mse(a, nz, keep, 1 / 0.9, loss2, 3e-5 / (M * D))
+    ar = a.clone().requires_grad_(True)
+    ref2 = 3e-5 * torch.nn.functional.mse_loss(ar * keep / 0.9, nz)
+    ref2.backward()
+    close(loss2, ref2.detach(), 1e-5, "dropout mse")
+    close(da, ar.grad, 1e-2, "dropout mse grad (bf16)")

@@ -1,0 +1,44 @@
+"""Micro-benchmark of dkd_gemm_nt / dkd_gemm_tn on the shapes of the headline step (teacher DeiT-base, student DeiT-tiny)."""
+import sys, os, time, json
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from deltakd_amd import ops
+
+dev = "cuda:0"
+BF16 = torch.bfloat16
+shapes = [  # (name, M, N, K, epilogue)
+    ("t_qkv", 50688, 2304, 768, "bias"), ("t_proj", 50688, 768, 768, "resid"), ("t_fc1", 50688, 3072, 768, "gelu"),
+    ("t_fc2", 50688, 768, 3072, "resid"), ("s_qkv", 50432, 576, 192, "bias"), ("s_fc1", 50432, 768, 192, "gelu"),
+    ("s_fc2", 50432, 192, 768, "resid"), ("s_proj", 50432, 192, 192, "resid"),
+]
+only = sys.argv[1:] 
+reps = 20
+res = {}
+for name, M, N, K, epi in shapes:
+    if only and name not in only: continue
+    a = torch.randn(M, K, device=dev).to(BF16)
+    b = (torch.randn(N, K, device=dev) * 0.05).to(BF16)
+    bias = torch.randn(N, device=dev)
+    kw = dict(bias=bias)
+    if epi == "gelu":
+        kw.update(gelu=True)
+    if epi == "resid":
+        kw.update(resid=torch.randn(M, N, device=dev), out_f32=True)
+    out = ops.gemm_nt(a, b, **kw)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        ops.gemm_nt(a, b, out=out, **kw)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    tf = 2.0 * M * N * K / ms / 1e9
+    res[name] = (ms * 1e3, tf)
+    print(f"{name:8s} M={M} N={N} K={K} {epi:6s} {ms*1e3:8.1f} us  {tf:7.1f} TFLOP/s", flush=True)
+# correctness spot check of the last shape
+ref = a[:512].float() @ b.float().t() + bias
+if epi == "resid":
+    ref = ref + kw["resid"][:512]
+err = (out[:512].float() - ref).abs().max().item() / ref.abs().max().item()
+print("spot-check rel err", err)

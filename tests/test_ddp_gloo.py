@@ -1,0 +1,75 @@
+"""The data-parallel wrapper on 2 CPU ranks (gloo): the gradient-averaging contract of SURVEY.md section 8(e)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+import torch.nn as nn
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+class FlatOpt:
+    """stand-in with FusedAdamW's hooks (grad_sync / flat_grads) on CPU tensors"""
+
+    def __init__(self, n):
+        self.flat = torch.zeros(n)
+        self.grad_sync = None
+
+    @property
+    def flat_grads(self):
+        return [self.flat]
+
+    def step(self):
+        self.grad_sync(self.flat_grads)
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from deltakd_amd.ddp import DataParallel
+    torch.manual_seed(100 + rank)                 # different init per rank: the wrapper must broadcast rank 0's
+    net = nn.Sequential(nn.Linear(8, 16), nn.ReLU(), nn.Linear(16, 4))
+    opt = FlatOpt(1000)
+    dp = DataParallel(net, opt, bucket_bytes=256)
+    w0 = [p.detach().clone() for p in net.parameters()]
+    x = torch.full((2, 8), float(rank + 1))
+    dp(x).sum().backward()
+    local = [p.grad.clone() for p in net.parameters()]
+    dp.sync_gradients()
+    synced = [p.grad.clone() for p in net.parameters()]
+    opt.flat.copy_(torch.arange(1000.) * (rank + 1))
+    opt.step()                                    # flat path: buckets of 64 floats
+    gathered = [None] * world
+    as_lists = lambda ts: [t.tolist() for t in ts]      # plain lists: no shared-memory handles through the queue
+    dist.all_gather_object(gathered, (as_lists(w0), as_lists(local), as_lists(synced), opt.flat.tolist()))
+    if rank == 0:
+        q.put(gathered)
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_two_rank_gradient_averaging():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = q.get(timeout=100)
+    for p in procs:
+        p.join(30)
+        assert p.exitcode == 0
+    T = torch.tensor
+    (w0a, la, sa, fa), (w0b, lb, sb, fb) = res
+    for a, b in zip(w0a, w0b):
+        assert torch.equal(T(a), T(b))            # parameters broadcast from rank 0
+    for ga, gb, xa, xb in zip(la, lb, sa, sb):
+        assert torch.allclose(T(xa), (T(ga) + T(gb)) / 2) and torch.equal(T(xa), T(xb))
+    assert torch.allclose(T(fa), torch.arange(1000.) * 1.5) and fa == fb

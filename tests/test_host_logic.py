@@ -1,0 +1,177 @@
+"""Host-side logic that needs no GPU: the step loop (with oracle models standing in for the HIP ones: the loop is
+model-agnostic), timm-shim semantics, optimizer grouping / schedule, error behaviour, the C ABI surface."""
+import math
+import os
+import re
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+from oracle import loss_ref, vit_ref
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TOY = dict(img_size=32, patch_size=8, mlp_ratio=2.0)
+
+
+def toy_pair(kind="lrkd"):
+    torch.manual_seed(0)
+    t = vit_ref.VisionTransformerRef(128, 12, 2, 10, True, 0.0, **TOY).eval()
+    s = vit_ref.VisionTransformerRef(64, 12, 1, 10, kind in ("soft", "hard"), 0.1, **TOY)
+    loss_ref.attach_aux_ref(s, t, kind, 16)
+    for p in t.parameters():
+        p.requires_grad = False
+    return s, t
+
+
+class OracleCriterion(nn.Module):
+    """reference call contract criterion(inputs, outputs, student, feats, labels, args) on the CPU oracle"""
+
+    def __init__(self, teacher, kind, args):
+        super().__init__()
+        self.inner = loss_ref.DistillationLossRef(loss_ref.call_base_loss_ref(args), teacher, kind, args.alpha, args.tau)
+
+    def forward(self, inputs, outputs, student, feats, labels, args):
+        return self.inner(inputs, outputs, student, feats, labels, args)
+
+
+@pytest.mark.parametrize("kind,mix", [("none", False), ("none", True), ("lrkd", True), ("soft", True)])
+def test_train_one_epoch_cpu_plumbing(kind, mix, monkeypatch):
+    """BASELINE config 1 ("plumbing, no GPU"): the de-duplicated step loop of SURVEY Appendix A runs end to end."""
+    from deltakd_amd import engine
+    from deltakd_amd.shims import Mixup, NativeScaler
+    s, t = toy_pair(kind)
+    args = loss_ref.default_args(distillation_type=kind, lrkd_rank=16, epochs=1, print_freq=0)
+    args.mixup = 0.8 if mix else 0.0
+    args.cutmix = 1.0 if mix else 0.0
+    # the oracle model has no forward_with_taps: hand the loop the oracle's feature tap
+    monkeypatch.setattr(engine, "forward_with_features", loss_ref.forward_with_features_ref)
+    g = torch.Generator().manual_seed(1)
+    loader = [(torch.randn(4, 3, 32, 32, generator=g), torch.randint(0, 10, (4,), generator=g)) for _ in range(3)]
+    opt = torch.optim.AdamW(s.parameters(), lr=1e-3)
+    before = s.head.weight.detach().clone()
+    np.random.seed(0)
+    mixup = Mixup(mixup_alpha=0.8, cutmix_alpha=1.0, num_classes=10) if mix else None
+    stats = engine.train_one_epoch(s, t, loader, OracleCriterion(t, kind, args), opt, NativeScaler(), None, mixup, None,
+                                   torch.device("cpu"), 0, args)
+    assert set(stats) == {"train_loss", "train_acc1", "train_acc5", "train_lr"}
+    assert all(math.isfinite(v) for v in stats.values()) and stats["train_lr"] == 1e-3
+    assert not torch.equal(before, s.head.weight) and args.current_epoch == 0
+    assert s.training and not t.training
+
+
+def test_mixup_shim_semantics():
+    from deltakd_amd.shims import Mixup, accuracy, mixup_target
+    np.random.seed(3)
+    x = torch.arange(4 * 3 * 8 * 8, dtype=torch.float32).view(4, 3, 8, 8)
+    y = torch.tensor([0, 1, 2, 3])
+    mix = Mixup(mixup_alpha=0.8, cutmix_alpha=0.0, num_classes=5, label_smoothing=0.1)
+    x0 = x.clone()
+    xm, ym = mix(x, y)
+    lam = ((xm - x0.flip(0)) / (x0 - x0.flip(0)))[0, 0, 0, 1].item()        # x = lam x + (1 - lam) flip(x)
+    assert 0 < lam < 1 and torch.allclose(xm, lam * x0 + (1 - lam) * x0.flip(0), atol=1e-3)
+    assert torch.allclose(ym.sum(1), torch.ones(4)) and torch.allclose(ym, mixup_target(y, 5, lam, 0.1), atol=1e-6)
+    assert abs(ym[0, 0].item() - (lam * (0.9 + 0.02) + (1 - lam) * 0.02)) < 1e-6
+    cut = Mixup(mixup_alpha=0.0, cutmix_alpha=1.0, num_classes=5)
+    x1 = torch.randn(4, 3, 8, 8)
+    x1c = x1.clone()
+    xc, yc = cut(x1, y)
+    changed = (xc != x1c).float().mean().item()
+    lam_c = yc[0, 0].item()          # with label_smoothing 0.1: on = 0.92, off = 0.02
+    assert abs((1 - changed) - (lam_c - 0.02) / 0.9) < 0.2                   # box area matches the corrected lambda
+    with pytest.raises(AssertionError):
+        mix(torch.zeros(3, 3, 8, 8), torch.tensor([0, 1, 2]))               # odd batch
+    out = torch.tensor([[0.1, 0.9, 0.0], [0.8, 0.1, 0.1]])
+    a1, a2 = accuracy(out, torch.tensor([1, 2]), topk=(1, 2))
+    assert a1.item() == 50.0 and a2.item() == 50.0
+
+
+def test_optimizer_groups_and_schedule():
+    from deltakd_amd.optim import CosineLRScheduler, param_groups_weight_decay
+    s, t = toy_pair("mgd")
+    groups = param_groups_weight_decay(s, 0.05, s.no_weight_decay())
+    named = dict(s.named_parameters())
+    no_decay = {id(p) for p in groups[0]["params"]}
+    for n in ("cls_token", "pos_embed", "blocks.0.norm1.weight", "blocks.3.attn.qkv.bias", "align.bias", "generation.0.bias"):
+        assert id(named[n]) in no_decay, n
+    for n in ("blocks.0.attn.qkv.weight", "patch_embed.proj.weight", "align.weight", "generation.2.weight", "mask_token"):
+        assert id(named[n]) not in no_decay, n
+    assert groups[0]["weight_decay"] == 0.0 and groups[1]["weight_decay"] == 0.05
+    opt = torch.optim.SGD([nn.Parameter(torch.zeros(1))], lr=5e-4)
+    sch = CosineLRScheduler(opt, t_initial=300, lr_min=1e-5, warmup_t=5, warmup_lr_init=1e-6)
+    assert opt.param_groups[0]["lr"] == 1e-6                      # timm starts at warmup_lr_init
+    sch.step(0)
+    assert opt.param_groups[0]["lr"] == 1e-6                      # the reference passes `epoch`, so epoch 1 repeats it
+    sch.step(3)
+    assert abs(opt.param_groups[0]["lr"] - (1e-6 + 3 * (5e-4 - 1e-6) / 5)) < 1e-12
+    sch.step(150)
+    assert abs(opt.param_groups[0]["lr"] - (1e-5 + 0.5 * (5e-4 - 1e-5))) < 1e-9
+    sch.step(300)
+    assert opt.param_groups[0]["lr"] == 1e-5
+
+
+def test_metric_logger_contract():
+    from deltakd_amd.logger import MetricLogger
+    ml = MetricLogger()
+    for v in (1.0, 2.0, torch.tensor(3.0)):
+        ml.update(loss=v)
+    assert ml.meters["loss"].global_avg == 2.0 and ml.meters["loss"].count == 3
+    seen = list(ml.log_every(range(5), 0, "x", rank=1))
+    assert seen == [0, 1, 2, 3, 4]
+
+
+def test_error_behaviour_matches_reference():
+    from deltakd_amd.losses import DistillationLoss, LabelSmoothingCrossEntropy
+    from deltakd_amd.models import forward_with_features
+    z = torch.zeros(2, 10)
+    args = loss_ref.default_args()
+    with pytest.raises(ValueError, match="Tuple"):       # model/loss.py:39-42
+        DistillationLoss(LabelSmoothingCrossEntropy(), nn.Identity(), "soft", 0.1, 3.0)(z, z, None, None, torch.zeros(2).long(), args)
+    with pytest.raises(ValueError, match="Invalid distillation type"):   # model/loss.py:238-239 (aaakd is accepted by argparse only)
+        DistillationLoss(LabelSmoothingCrossEntropy(), nn.Identity(), "aaakd", 0.1, 3.0)(z, z, None, None, torch.zeros(2).long(), args)
+    assert forward_with_features(nn.Linear(2, 2), torch.zeros(1, 2)) == (None, None)      # model/models.py:182-183
+
+
+def test_product_path_has_no_cpu_fallback():
+    from deltakd_amd import ops, vit
+    m = vit.VisionTransformer(64, 2, 1, 10, False, 0.0, **TOY)
+    with pytest.raises(RuntimeError, match="MI355X"):
+        m(torch.zeros(2, 3, 32, 32))
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        ops.layernorm_fwd(torch.zeros(4, 64), torch.ones(64), torch.zeros(64))
+    # and nothing under deltakd_amd/ imports the oracle
+    for dp, _, files in os.walk(os.path.join(ROOT, "deltakd_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                assert not re.search(r"^\s*(from|import)\s+oracle", open(os.path.join(dp, f)).read(), re.M), f
+
+
+def test_state_dict_keys_are_timm_compatible():
+    from deltakd_amd import vit
+    from deltakd_amd.models import attach_aux
+    hip = vit.VisionTransformer(64, 12, 1, 10, True, 0.1, **TOY)
+    ref = vit_ref.VisionTransformerRef(64, 12, 1, 10, True, 0.1, **TOY)
+    assert set(hip.state_dict()) == set(ref.state_dict())
+    assert {k: v.shape for k, v in hip.state_dict().items()} == {k: v.shape for k, v in ref.state_dict().items()}
+    for kind in ("lrkd", "mgd", "diffkd", "wasskd"):
+        a = attach_aux(vit.VisionTransformer(64, 12, 1, 10, False, 0.1, **TOY), hip, kind, SimpleNamespace(lrkd_rank=16))
+        b = loss_ref.attach_aux_ref(vit_ref.VisionTransformerRef(64, 12, 1, 10, False, 0.1, **TOY), ref, kind, 16)
+        assert {k: v.shape for k, v in a.state_dict().items()} == {k: v.shape for k, v in b.state_dict().items()}, kind
+
+
+def test_c_abi_library_exports_every_declared_symbol():
+    """The shared library loads without a GPU and exports exactly the entry points include/dkd.h declares."""
+    from deltakd_amd import ffi
+    header = open(os.path.join(ROOT, "include", "dkd.h")).read()
+    declared = set(re.findall(r"^(?:int|const char\*)\s+(dkd_\w+)\s*\(", header, re.M))
+    assert declared, "no declarations parsed"
+    handle = ffi.lib()
+    for name in declared:
+        assert hasattr(handle, name), f"{name} declared in dkd.h but not exported by libdkd.so"
+    assert declared == set(ffi.EXPORTS), declared ^ set(ffi.EXPORTS)
+    assert handle.dkd_version() >= 100
+    # argument errors come back through the error channel, not as crashes (no kernel is launched for a bad call)
+    rc = handle.dkd_gemm_nt(None, None)
+    assert rc == -1 and b"null" in handle.dkd_last_error()

@@ -1,0 +1,123 @@
+#!/usr/bin/env python3
+"""Training CLI with the flag surface of /root/reference/tools/train.py:22-212 so the exp/*.sh scripts run unchanged
+(``torchrun --nproc_per_node=N tools/train.py --student-model ... --distillation-type ...``).
+
+Orchestration only (out of scope as an acceleration target).  The hot path it drives is
+deltakd_amd: HIP models, fused losses, FusedAdamW, RCCL data parallel.  Datasets: torchvision is absent on the MI355X
+boxes and nothing can be downloaded, so ``--data-path`` is only used when torchvision is importable; otherwise (or with
+``--synthetic-batches N``) batches are synthetic tensors of the dataset's shape and class count, generated on the device.
+Not carried over: wandb, thop FLOP counting, checkpoint save/resume/finetune, EMA (all I/O or disabled by default).
+"""
+import argparse
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from deltakd_amd.ddp import DataParallel  # noqa: E402
+from deltakd_amd.engine import train_one_epoch, validate  # noqa: E402
+from deltakd_amd.losses import DistillationLoss, call_base_loss  # noqa: E402
+from deltakd_amd.models import DATASET_NUM_CLASSES, load_teacher_student_model  # noqa: E402
+from deltakd_amd.optim import create_optimizer, create_scheduler  # noqa: E402
+from deltakd_amd.shims import Mixup, NativeScaler  # noqa: E402
+from tools.utils import seed_everything, setup_device, setup_distributed  # noqa: E402
+
+DISTILL_TYPES = ['none', 'soft', 'hard', 'vitkd', 'aaakd', 'vitkd_w_logit', 'aaakd_w_logit', 'lrkd', 'diffkd', 'saliency_mgd', 'curkd',
+                 'wasskd', 'mgd']
+
+
+def parse_args(argv=None):
+    p = argparse.ArgumentParser(description="ViT knowledge-distillation training on MI355X (reference-compatible flags)")
+    S, F, I = str, float, int
+    typed = [  # (flag, type, default)
+        ("--teacher-model", S, "deit_small_distilled_patch16_224"), ("--student-model", S, "deit_tiny_patch16_224"),
+        ("--input-size", I, 224), ("--batch-size", I, 256), ("--ema-decay", F, None), ("--label-smoothing", F, 0.1),
+        ("--drop-path-rate", F, 0.1), ("--num-workers", I, 10), ("--epochs", I, 300),
+        ("--opt", S, "adamw"), ("--opt-eps", F, 1e-8), ("--clip-grad", F, None), ("--momentum", F, 0.9), ("--weight-decay", F, 0.05),
+        ("--sched", S, "cosine"), ("--lr", F, 5e-4), ("--lr-noise-pct", F, 0.67), ("--lr-noise-std", F, 1.0), ("--warmup-lr", F, 1e-6),
+        ("--min-lr", F, 1e-5), ("--decay-epochs", F, 30), ("--warmup-epochs", I, 5), ("--cooldown-epochs", I, 10),
+        ("--patience-epochs", I, 10), ("--decay-rate", F, 0.1), ("--gpus", S, None), ("--dist-url", S, "env://"),
+        ("--alpha", F, 0.1), ("--tau", F, 3.0), ("--lrkd-rank", I, 32), ("--lrkd-alpha", F, 0.1), ("--lrkd-beta", F, 0.1),
+        ("--lrkd-gamma", F, 0.1), ("--saliency-method", I, 1), ("--saliency-mask-ratio", F, 0.5), ("--wasskd-type", S, "l1"),
+        ("--mgd-alpha", F, 7e-5), ("--mgd-mask-ratio", F, 0.5), ("--log-file", S, "logs/train.log"), ("--save-dir", S, "checkpoints"),
+        ("--wandb-project", S, "distill-vit"), ("--data-path", S, "dataset"), ("--dataset", S, "imagenet-1k"),
+        ("--eval-crop-ratio", F, 0.875), ("--mixup", F, 0.8), ("--cutmix", F, 1.0), ("--mixup-prob", F, 1.0),
+        ("--mixup-switch-prob", F, 0.5), ("--mixup-mode", S, "batch"), ("--reprob", F, 0.25), ("--remode", S, "pixel"),
+        ("--recount", I, 1), ("--color-jitter", F, 0.3), ("--aa", S, "rand-m9-mstd0.5-inc1"), ("--smoothing", F, 0.1),
+        ("--interpolation", S, "bicubic"), ("--checkpoint", S, None), ("--seed", I, 42), ("--device", S, None),
+        ("--teacher-checkpoint", S, None), ("--synthetic-batches", I, 0),
+    ]
+    for flag, ty, default in typed:
+        p.add_argument(flag, type=ty, default=default)
+    p.add_argument("--dr", dest="decay_rate", type=F)
+    for flag in ("--fp16", "--amp", "--wandb", "--resplit", "--ThreeAugment", "--src", "--resume", "--finetune"):
+        p.add_argument(flag, action="store_true")
+    p.add_argument("--pin-mem", action="store_true", default=True)
+    p.add_argument("--repeated-aug", action="store_true", default=True)
+    p.add_argument("--no-repeated-aug", action="store_false", dest="repeated_aug")
+    for flag in ("--opt-betas", "--lr-noise", "--cutmix-minmax"):
+        p.add_argument(flag, type=F, nargs="+", default=None)
+    p.add_argument("--distillation-type", type=S, choices=DISTILL_TYPES, default="none")
+    return p.parse_args(argv)
+
+
+class SyntheticLoader:
+    """N batches of N(0,1) images / uniform labels generated on the device (ImageNet-normalised images are ~N(0,1))."""
+
+    def __init__(self, n, batch, size, classes, device, seed):
+        self.n, self.batch, self.size, self.classes, self.device = n, batch, size, classes, device
+        self.gen = torch.Generator(device=device).manual_seed(seed)
+
+    def __len__(self):
+        return self.n
+
+    def __iter__(self):
+        for _ in range(self.n):
+            yield (torch.randn(self.batch, 3, self.size, self.size, device=self.device, generator=self.gen),
+                   torch.randint(0, self.classes, (self.batch,), device=self.device, generator=self.gen))
+
+
+def main(argv=None):
+    args = parse_args(argv)
+    setup_distributed(args)
+    device = setup_device(args)
+    seed_everything(args.seed)
+    np.random.seed(args.seed + args.rank)
+    if args.rank == 0:
+        print(args)
+    teacher, student = load_teacher_student_model(args.teacher_model, args.student_model, args.drop_path_rate, args)
+    student.to(device)
+    teacher.to(device)
+    classes = DATASET_NUM_CLASSES[args.dataset]
+    n_batches = args.synthetic_batches or 10
+    train_loader = SyntheticLoader(n_batches, args.batch_size, args.input_size, classes, device, args.seed + args.rank)
+    val_loader = SyntheticLoader(2, args.batch_size, args.input_size, classes, device, 10_000 + args.rank)
+
+    optimizer = create_optimizer(args, student)
+    scheduler, _ = create_scheduler(args, optimizer)
+    loss_scaler = NativeScaler()
+    mixup_active = args.mixup > 0 or args.cutmix > 0. or args.cutmix_minmax is not None
+    mixup_fn = Mixup(mixup_alpha=args.mixup, cutmix_alpha=args.cutmix, cutmix_minmax=args.cutmix_minmax, prob=args.mixup_prob,
+                     switch_prob=args.mixup_switch_prob, mode=args.mixup_mode, label_smoothing=args.smoothing,
+                     num_classes=classes) if mixup_active else None
+    criterion = DistillationLoss(call_base_loss(args), teacher, args.distillation_type, args.alpha, args.tau,
+                                 teacher_stream=torch.cuda.Stream() if device.type == "cuda" else None)
+    model = DataParallel(student, optimizer) if args.distributed else student
+    for epoch in range(args.epochs):
+        tm = train_one_epoch(student_model=model, teacher_model=teacher, train_loader=train_loader, criterion=criterion,
+                             optimizer=optimizer, loss_scaler=loss_scaler, clip_grad=args.clip_grad, mixup_fn=mixup_fn, model_ema=None,
+                             device=device, epoch=epoch, args=args)
+        scheduler.step(epoch)
+        vm = validate(model, val_loader, device, args)
+        if args.rank == 0:
+            print(f"Epoch {epoch} - Train: {tm} - Val: {vm}")
+    if args.distributed:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

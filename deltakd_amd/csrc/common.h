@@ -46,9 +46,21 @@ __device__ __forceinline__ int map_row(const DkdRowMap& m, int r) {
   return m.rpg > 0 ? (r / m.rpg) * m.gstride + (r % m.rpg) + m.off : r;
 }
 
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+// erf by Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7, i.e. at fp32 roundoff of the GELU it feeds): one v_exp + one v_rcp
+// instead of libm's branchy erff -- the GELU epilogue of the fc1 GEMM was VALU-bound on erff.
+__device__ __forceinline__ float fast_erf(float x) {
+  const float ax = fabsf(x);
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));   // v_rcp_f32 (1 ulp): __frcp_rn expands to a full IEEE division
+  float p = fmaf(1.061405429f, t, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  const float r = 1.0f - p * t * __expf(-ax * ax);
+  return copysignf(r, x);
+}
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + fast_erf(x * 0.70710678118654752f)); }
 __device__ __forceinline__ float dgelu_erf(float x) {
-  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
+  const float cdf = 0.5f * (1.0f + fast_erf(x * 0.70710678118654752f));
   const float pdf = 0.3989422804014327f * __expf(-0.5f * x * x);
   return cdf + x * pdf;
 }

@@ -12,6 +12,7 @@
 //    read with ds_read_b64_tr_b16 (hardware transpose), so no transposed activation copy ever exists in HBM.
 //  * epilogue goes through LDS so that bias / GELU / residual / DropPath-scale / feature-tap traffic is 16-B coalesced.
 //  * blockIdx -> tile map is XCD-aware (each XCD's L2 sees a contiguous run of tiles sharing A panels).
+#include <stdlib.h>
 #include "common.h"
 
 namespace {
@@ -49,13 +50,145 @@ __device__ __forceinline__ float epi_scalar(const DkdGemm& g, float v, int m, in
   return v;
 }
 
-template <int BN>
+// Epilogue operands that come from memory (residual row, GELU pre-activation) are fetched for a whole batch of output
+// vectors BEFORE any of them is stored: C may alias resid (in-place residual), so the compiler cannot hoist a load above an
+// earlier store and a load->store->load chain would expose one full memory latency per vector.
+// Each lane owns 8 consecutive columns of one row: every bf16 access is a full 16-B dwordx4 (store-issue bound otherwise).
+typedef __attribute__((ext_vector_type(8))) float f32x8;
+struct EpiIn {
+  f32x4 r0, r1;
+  uint4 pre;
+};
+__device__ __forceinline__ f32x8 unpack8(const uint4 p) {
+  return f32x8{__uint_as_float(p.x << 16), __uint_as_float(p.x & 0xffff0000u), __uint_as_float(p.y << 16), __uint_as_float(p.y & 0xffff0000u),
+               __uint_as_float(p.z << 16), __uint_as_float(p.z & 0xffff0000u), __uint_as_float(p.w << 16), __uint_as_float(p.w & 0xffff0000u)};
+}
+__device__ __forceinline__ uint4 pack8(const f32x8& v) {
+  return uint4{pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7])};
+}
+__device__ __forceinline__ EpiIn epi_prefetch(const DkdGemm& g, const int vec_ok, const int m, const int n) {
+  EpiIn in;
+  in.r0 = in.r1 = f32x4{0.f, 0.f, 0.f, 0.f};
+  in.pre = uint4{0u, 0u, 0u, 0u};
+  if (vec_ok) {
+    if (g.epi & DKD_EPI_RESID) {
+      const float* rp = &g.resid[(size_t)map_row(g.rmap, m) * g.ldr + n];
+      in.r0 = *(const f32x4*)rp;
+      in.r1 = *(const f32x4*)(rp + 4);
+    }
+    if (g.epi & DKD_EPI_DGELU) in.pre = *(const uint4*)&((const bf16_t*)g.preact)[(size_t)m * g.ldp + n];
+  }
+  return in;
+}
+__device__ __forceinline__ void epi_finish(const DkdGemm& g, const int vec_ok, f32x8 v, const EpiIn& in, const int m, const int n) {
+  const bool out_f32 = g.epi & DKD_EPI_OUT_F32;
+  const size_t crow = (size_t)map_row(g.cmap, m) * g.ldc;
+  if (vec_ok) {
+    if (g.epi & DKD_EPI_BIAS) {
+      const f32x4 b0 = *(const f32x4*)&g.bias[n], b1 = *(const f32x4*)&g.bias[n + 4];
+      v += f32x8{b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+    }
+    if (g.epi & DKD_EPI_GELU) {
+      if (g.preact) *(uint4*)&((bf16_t*)g.preact)[(size_t)m * g.ldp + n] = pack8(v);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = gelu_erf(v[e]);
+    }
+    if (g.epi & DKD_EPI_DGELU) {
+      const f32x8 p = unpack8(in.pre);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] *= dgelu_erf(p[e]);
+    }
+    if (g.epi & DKD_EPI_RELU) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+    }
+    if (g.tap) {
+      if (g.epi & DKD_EPI_TAP_F32) {
+        float* tp = &((float*)g.tap)[(size_t)m * g.ldt + n];
+        *(f32x4*)tp = f32x4{v[0], v[1], v[2], v[3]};
+        *(f32x4*)(tp + 4) = f32x4{v[4], v[5], v[6], v[7]};
+      } else {
+        *(uint4*)&((bf16_t*)g.tap)[(size_t)m * g.ldt + n] = pack8(v);
+      }
+    }
+    if (g.epi & DKD_EPI_RESID) {
+      const float sc = g.rowscale ? g.rowscale[m / g.rows_per_sample] : 1.f;
+      v = f32x8{in.r0[0], in.r0[1], in.r0[2], in.r0[3], in.r1[0], in.r1[1], in.r1[2], in.r1[3]} + sc * v;
+    }
+    if (out_f32) {
+      float* cp = (float*)g.C + crow + n;
+      f32x4 lo = {v[0], v[1], v[2], v[3]}, hi = {v[4], v[5], v[6], v[7]};
+      if (g.epi & DKD_EPI_ACCUM) {
+        lo += *(const f32x4*)cp;
+        hi += *(const f32x4*)(cp + 4);
+      }
+      *(f32x4*)cp = lo;
+      *(f32x4*)(cp + 4) = hi;
+    } else {
+      *(uint4*)((bf16_t*)g.C + crow + n) = pack8(v);
+    }
+  } else {
+    for (int e = 0; e < 8 && n + e < g.N; ++e) {
+      float x = epi_scalar(g, v[e], m, n + e);
+      if (out_f32) {
+        float* cp = (float*)g.C + crow + n + e;
+        if (g.epi & DKD_EPI_ACCUM) x += *cp;
+        *cp = x;
+      } else {
+        ((bf16_t*)g.C)[crow + n + e] = f2bf(x);
+      }
+    }
+  }
+}
+
+// ---- epilogue shared by the 128-row NT kernels: ONE pass through LDS (f32 [128][BN], unpadded: the accumulator-layout
+// ds_write_b32 is only 2-way per 32-lane group = free, the row reads are contiguous), then 16-B coalesced fused stores.
+template <int BN, int NJ>
+__device__ __forceinline__ void nt_epilogue(const DkdGemm& g, const int vec_ok, char* smem, f32x4 (&acc)[4][NJ], const int m0,
+                                            const int n0, const int tid, const int wr, const int wc) {
+  const int lane = tid & 63, frow = lane & 15, fg = lane >> 4;
+  float* cs = (float*)smem;
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) cs[(wr * 64 + i * 16 + fg * 4 + r) * BN + wc * (BN / 2) + j * 16 + frow] = acc[i][j][r];
+  __syncthreads();
+  constexpr int TPR = BN / 8;            // threads per output row (8 columns each)
+  constexpr int RPP = 256 / TPR;         // rows per sweep of the 256 threads
+  const int col8 = (tid % TPR) * 8, r0 = tid / TPR;
+  const int n = n0 + col8;
+  if (n >= g.N) return;
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    constexpr int SW = 64 / RPP;         // sweeps per 64-row half
+    EpiIn in[SW];
+#pragma unroll
+    for (int s = 0; s < SW; ++s) {
+      const int m = m0 + half * 64 + r0 + RPP * s;
+      if (m < g.M) in[s] = epi_prefetch(g, vec_ok, m, n);
+    }
+#pragma unroll
+    for (int s = 0; s < SW; ++s) {
+      const int rl = half * 64 + r0 + RPP * s;
+      const int m = m0 + rl;
+      if (m < g.M) {
+        const f32x4 lo = *(const f32x4*)&cs[rl * BN + col8], hi = *(const f32x4*)&cs[rl * BN + col8 + 4];
+        epi_finish(g, vec_ok, f32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]}, in[s], m, n);
+      }
+    }
+  }
+}
+
+template <int BN, int ABL = 0>   // ABL (dev ablation): 1 = no epilogue, 2 = no main loop
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const DkdGemm g, const int vec_ok) {
   constexpr int NJ = BN / 32;             // 16-col MFMA tiles per wave along N
   constexpr int A_BYTES = BM * 128;       // 16 KiB
   constexpr int B_BYTES = BN * 128;
   constexpr int BUF = A_BYTES + B_BYTES;
-  constexpr int SMEM = (2 * BUF) > (64 * CS_LD * 4) ? (2 * BUF) : (64 * CS_LD * 4);
+  constexpr int SMEM = (2 * BUF) > (128 * BN * 4) ? (2 * BUF) : (128 * BN * 4);
   __shared__ __attribute__((aligned(16))) char smem[SMEM];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -64,7 +197,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const DkdGemm g, const 
   const int tiles_n = (g.N + BN - 1) / BN;
   const int L = xcd_remap(blockIdx.x, gridDim.x);
   const int m0 = (L / tiles_n) * BM, n0 = (L % tiles_n) * BN;
-  const int KT = g.K / BK;
+  const int KT = ABL == 2 ? 0 : g.K / BK;
 
   // per-lane source rows for the LDS-DMA staging: 1 KiB chunk = 8 rows x 128 B; lane -> (row = lane>>3, slot = lane&7)
   const bf16_t* arow[4];
@@ -109,7 +242,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const DkdGemm g, const 
 
   const int frow = lane & 15, fg = lane >> 4, fswz = (frow >> 1) & 7;
 
-  stage(0, 0);
+  if (ABL != 2) stage(0, 0);
   for (int kt = 0; kt < KT; ++kt) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -131,84 +264,101 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const DkdGemm g, const 
     }
   }
 
-  // ---- epilogue: 2 passes of 64 rows through LDS (f32), then 16-B coalesced fused stores
-  float* cs = (float*)smem;
-  const int col4 = (tid & 31) * 4;
-  const bool out_f32 = g.epi & DKD_EPI_OUT_F32;
-  for (int h = 0; h < 2; ++h) {
-    __syncthreads();
-    if (wr == h) {
+  if (ABL == 1) {      // keep the accumulators live without an epilogue
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) t += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+    if (t == 123456.789f) ((float*)g.C)[tid] = t;
+    return;
+  }
+  nt_epilogue<BN, NJ>(g, vec_ok, smem, acc, m0, n0, tid, wr, wc);
+}
+
+// ---- multi-stage variant: STAGES LDS buffers of 128 x BKP, LDS-DMA prefetch STAGES-1 k-tiles ahead kept in flight
+// across a raw s_barrier with a counted s_waitcnt vmcnt(N) (cdna_hip_programming "Pipelining across barriers").
+template <int BKP, int STAGES, int OCC>
+__global__ __launch_bounds__(256, OCC) void gemm_nt_pipe_kernel(const DkdGemm g, const int vec_ok) {
+  constexpr int BN = 128, NJ = 4;
+  constexpr int ROWB = BKP * 2;                 // bytes per tile row
+  constexpr int SLOTS = BKP / 8;                // 16-B slots per row
+  constexpr int RPC = 1024 / ROWB;              // rows per 1 KiB LDS-DMA chunk
+  constexpr int TILE = 128 * ROWB;              // bytes of one operand tile
+  constexpr int BUF = 2 * TILE;
+  constexpr int CH = 128 / RPC / 4;             // chunks per wave per operand
+  constexpr int GL = 2 * CH;                    // LDS-DMA instructions per wave per stage
+  constexpr int SMEM = (STAGES * BUF) > (128 * BN * 4) ? (STAGES * BUF) : (128 * BN * 4);
+  __shared__ __attribute__((aligned(16))) char smem[SMEM];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = w >> 1, wc = w & 1;
+  const int tiles_n = (g.N + BN - 1) / BN;
+  const int L = xcd_remap(blockIdx.x, gridDim.x);
+  const int m0 = (L / tiles_n) * BM, n0 = (L % tiles_n) * BN;
+  const int KT = g.K / BKP;
+
+  auto swz = [](int row) { return BKP == 64 ? ((row >> 1) & 7) : (((row >> 2) & 1) << 1); };
+
+  const bf16_t* arow[CH];
+  const bf16_t* brow[CH];
+  int slot[CH];
+#pragma unroll
+  for (int c = 0; c < CH; ++c) {
+    const int r = w * 32 + c * RPC + lane / SLOTS;
+    int m = m0 + r, n = n0 + r;
+    m = m < g.M ? m : g.M - 1;
+    n = n < g.N ? n : g.N - 1;
+    arow[c] = (const bf16_t*)g.A + (size_t)map_row(g.amap, m) * g.lda;
+    brow[c] = (const bf16_t*)g.B + (size_t)n * g.ldb;
+    slot[c] = ((lane % SLOTS) ^ swz(r)) * 8;
+  }
+  auto stage = [&](int kt) {
+    char* abase = smem + (kt % STAGES) * BUF;
+    char* bbase = abase + TILE;
+    const int k0 = kt * BKP;
+#pragma unroll
+    for (int c = 0; c < CH; ++c)
+      __builtin_amdgcn_global_load_lds(GLB_PTR(arow[c] + k0 + slot[c]), LDS_PTR(abase + (w * 32 + c * RPC) * ROWB), 16, 0, 0);
+#pragma unroll
+    for (int c = 0; c < CH; ++c)
+      __builtin_amdgcn_global_load_lds(GLB_PTR(brow[c] + k0 + slot[c]), LDS_PTR(bbase + (w * 32 + c * RPC) * ROWB), 16, 0, 0);
+  };
+
+  f32x4 acc[4][NJ];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int frow = lane & 15, fg = lane >> 4, fswz = swz(frow);
+
+#pragma unroll
+  for (int s = 0; s < STAGES - 1; ++s)
+    if (s < KT) stage(s);
+  for (int kt = 0; kt < KT; ++kt) {
+    // tile kt must have landed; the newer (STAGES-2) tiles may stay in flight
+    if (kt + STAGES - 2 < KT) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * GL) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (kt + STAGES - 1 < KT) stage(kt + STAGES - 1);   // overwrites the buffer read in iteration kt-1 (all waves are past it)
+    const char* abase = smem + (kt % STAGES) * BUF;
+    const char* bbase = abase + TILE;
+#pragma unroll
+    for (int kk = 0; kk < BKP / 32; ++kk) {
+      const int ps = ((kk * 4 + fg) ^ fswz) * 16;
+      bf16x8 a[4], b[NJ];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a[i] = *(const bf16x8*)(abase + (wr * 64 + i * 16 + frow) * ROWB + ps);
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) b[j] = *(const bf16x8*)(bbase + (wc * 64 + j * 16 + frow) * ROWB + ps);
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < NJ; ++j)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) cs[(i * 16 + fg * 4 + r) * CS_LD + wc * (BN / 2) + j * 16 + frow] = acc[i][j][r];
-    }
-    __syncthreads();
-    if (col4 < BN) {
-      for (int s = 0; s < 8; ++s) {
-        const int rl = (tid >> 5) + 8 * s;
-        const int m = m0 + h * 64 + rl, n = n0 + col4;
-        if (m >= g.M || n >= g.N) continue;
-        const size_t crow = (size_t)map_row(g.cmap, m) * g.ldc;
-        f32x4 v = *(const f32x4*)&cs[rl * CS_LD + col4];
-        if (vec_ok) {
-          if (g.epi & DKD_EPI_BIAS) v += *(const f32x4*)&g.bias[n];
-          if (g.epi & DKD_EPI_GELU) {
-            if (g.preact) {
-              uint2 pk = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
-              *(uint2*)&((bf16_t*)g.preact)[(size_t)m * g.ldp + n] = pk;
-            }
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
-          }
-          if (g.epi & DKD_EPI_DGELU) {
-            const uint2 pk = *(const uint2*)&((const bf16_t*)g.preact)[(size_t)m * g.ldp + n];
-            v[0] *= dgelu_erf(__uint_as_float(pk.x << 16));
-            v[1] *= dgelu_erf(__uint_as_float(pk.x & 0xffff0000u));
-            v[2] *= dgelu_erf(__uint_as_float(pk.y << 16));
-            v[3] *= dgelu_erf(__uint_as_float(pk.y & 0xffff0000u));
-          }
-          if (g.epi & DKD_EPI_RELU) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-          }
-          if (g.tap) {
-            if (g.epi & DKD_EPI_TAP_F32) *(f32x4*)&((float*)g.tap)[(size_t)m * g.ldt + n] = v;
-            else {
-              uint2 pk = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
-              *(uint2*)&((bf16_t*)g.tap)[(size_t)m * g.ldt + n] = pk;
-            }
-          }
-          if (g.epi & DKD_EPI_RESID) {
-            const float sc = g.rowscale ? g.rowscale[m / g.rows_per_sample] : 1.f;
-            const f32x4 rv = *(const f32x4*)&g.resid[(size_t)map_row(g.rmap, m) * g.ldr + n];
-            v = rv + sc * v;
-          }
-          if (out_f32) {
-            float* cp = (float*)g.C + crow + n;
-            if (g.epi & DKD_EPI_ACCUM) v += *(const f32x4*)cp;
-            *(f32x4*)cp = v;
-          } else {
-            uint2 pk = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
-            *(uint2*)((bf16_t*)g.C + crow + n) = pk;
-          }
-        } else {
-          for (int e = 0; e < 4 && n + e < g.N; ++e) {
-            float x = epi_scalar(g, v[e], m, n + e);
-            if (out_f32) {
-              float* cp = (float*)g.C + crow + n + e;
-              if (g.epi & DKD_EPI_ACCUM) x += *cp;
-              *cp = x;
-            } else {
-              ((bf16_t*)g.C)[crow + n + e] = f2bf(x);
-            }
-          }
-        }
-      }
+        for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
     }
   }
+  nt_epilogue<BN, NJ>(g, vec_ok, smem, acc, m0, n0, tid, wr, wc);
 }
 
 // ------------------------------------------------------------------------------------------------ TN (wgrad)
@@ -216,7 +366,7 @@ constexpr int TN_LD = 288;                 // bytes per LDS row (256 B of data +
 constexpr int TN_TILE = 64 * TN_LD;        // 18 KiB per operand tile
 __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, float* C,
                                                          int M, int N1, int N2, int lda, int ldb, int ldc, DkdRowMap amap,
-                                                         DkdRowMap bmap, int kt_per_split) {
+                                                         DkdRowMap bmap, int kt_per_split, float* __restrict__ a_colsum) {
   __shared__ __attribute__((aligned(16))) char smem[4 * TN_TILE];  // [buf][A|B] ; reused by the epilogue (33 KiB)
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -231,6 +381,9 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const bf16_t* __restric
 
   const int lrow = tid >> 4, lcol = (tid & 15) * 8;  // staging: thread -> (row lrow + 16 c, 8 elements at lcol)
   s16x8 ra[4], rb[4];
+  // fused bias gradient: column sums of the A operand (dY) ride along in the blocks of the first N2 tile
+  const bool do_colsum = a_colsum != nullptr && t2 == 0;
+  float csum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   auto gload = [&](int kt) {
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
@@ -250,6 +403,10 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const bf16_t* __restric
       }
       ra[c] = va;
       rb[c] = vb;
+      if (do_colsum) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) csum[e] += __uint_as_float(((uint32_t)(uint16_t)va[e]) << 16);
+      }
     }
   };
   auto lstore = [&](int buf) {
@@ -308,8 +465,20 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const bf16_t* __restric
     __syncthreads();
   }
 
-  // epilogue: stage through LDS, then 256-B contiguous f32 atomics per wave-instruction
   float* cs = (float*)smem;
+  if (do_colsum) {   // 16 row-lanes (tid >> 4) hold partial sums of the same 8 columns: combine through LDS
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 8; ++e) cs[lrow * 128 + lcol + e] = csum[e];
+    __syncthreads();
+    if (tid < 128 && n1_0 + tid < N1) {
+      float t = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) t += cs[r * 128 + tid];
+      atomicAdd(&a_colsum[n1_0 + tid], t);
+    }
+  }
+  // epilogue: stage through LDS, then 256-B contiguous f32 atomics per wave-instruction
   for (int h = 0; h < 2; ++h) {
     __syncthreads();
     if (wr == h) {
@@ -343,13 +512,32 @@ extern "C" int dkd_gemm_nt(const DkdGemm* gp, void* stream) {
   DKD_CHECK_ARG(!(g.epi & DKD_EPI_DGELU) || g.preact, "gemm_nt: DGELU without preact pointer");
   DKD_CHECK_ARG(!(g.epi & DKD_EPI_ACCUM) || (g.epi & DKD_EPI_OUT_F32), "gemm_nt: ACCUM needs f32 output");
   DKD_CHECK_ARG(!g.rowscale || g.rows_per_sample > 0, "gemm_nt: rowscale needs rows_per_sample");
-  int vec_ok = (g.N % 4 == 0) && (g.ldc % 4 == 0) && (((uintptr_t)g.C & 15) == 0);
+  int vec_ok = (g.N % 8 == 0) && (g.ldc % 8 == 0) && (((uintptr_t)g.C & 15) == 0);
   if (g.epi & DKD_EPI_BIAS) vec_ok = vec_ok && (((uintptr_t)g.bias & 15) == 0);
-  if (g.epi & DKD_EPI_RESID) vec_ok = vec_ok && (g.ldr % 4 == 0) && (((uintptr_t)g.resid & 15) == 0);
-  if (g.preact) vec_ok = vec_ok && (g.ldp % 4 == 0) && (((uintptr_t)g.preact & 7) == 0);
-  if (g.tap) vec_ok = vec_ok && (g.ldt % 4 == 0) && (((uintptr_t)g.tap & 15) == 0);
+  if (g.epi & DKD_EPI_RESID) vec_ok = vec_ok && (g.ldr % 8 == 0) && (((uintptr_t)g.resid & 15) == 0);
+  if (g.preact) vec_ok = vec_ok && (g.ldp % 8 == 0) && (((uintptr_t)g.preact & 15) == 0);
+  if (g.tap) vec_ok = vec_ok && (g.ldt % 8 == 0) && (((uintptr_t)g.tap & 15) == 0);
   const bool narrow = (g.N % 128 != 0) && (g.N % 128 <= 64);
   const int tiles_m = cdiv(g.M, BM);
+  static const int variant = getenv("DKD_GEMM_VARIANT") ? atoi(getenv("DKD_GEMM_VARIANT")) : 0;   // dev knob: pipeline shape
+  if ((variant == 10 || variant == 11) && !narrow) {
+    if (variant == 10) hipLaunchKernelGGL((gemm_nt_kernel<128, 1>), dim3(tiles_m * cdiv(g.N, 128)), dim3(256), 0, as_stream(stream), g, vec_ok);
+    else hipLaunchKernelGGL((gemm_nt_kernel<128, 2>), dim3(tiles_m * cdiv(g.N, 128)), dim3(256), 0, as_stream(stream), g, vec_ok);
+    DKD_CHECK_LAUNCH("gemm_nt ablation");
+    return DKD_OK;
+  }
+  if (!narrow && variant > 0 && variant < 6) {
+    const dim3 grid(tiles_m * cdiv(g.N, 128));
+    switch (variant) {
+      case 1: hipLaunchKernelGGL((gemm_nt_pipe_kernel<64, 2, 2>), grid, dim3(256), 0, as_stream(stream), g, vec_ok); break;
+      case 2: hipLaunchKernelGGL((gemm_nt_pipe_kernel<32, 3, 3>), grid, dim3(256), 0, as_stream(stream), g, vec_ok); break;
+      case 3: hipLaunchKernelGGL((gemm_nt_pipe_kernel<32, 4, 2>), grid, dim3(256), 0, as_stream(stream), g, vec_ok); break;
+      case 4: hipLaunchKernelGGL((gemm_nt_pipe_kernel<32, 3, 2>), grid, dim3(256), 0, as_stream(stream), g, vec_ok); break;
+      default: hipLaunchKernelGGL((gemm_nt_pipe_kernel<64, 3, 1>), grid, dim3(256), 0, as_stream(stream), g, vec_ok); break;
+    }
+    DKD_CHECK_LAUNCH("gemm_nt");
+    return DKD_OK;
+  }
   if (narrow) {
     hipLaunchKernelGGL(gemm_nt_kernel<64>, dim3(tiles_m * cdiv(g.N, 64)), dim3(256), 0, as_stream(stream), g, vec_ok);
   } else {
@@ -360,7 +548,7 @@ extern "C" int dkd_gemm_nt(const DkdGemm* gp, void* stream) {
 }
 
 extern "C" int dkd_gemm_tn(const void* A, const void* B, float* C, int32_t M, int32_t N1, int32_t N2, int32_t lda, int32_t ldb,
-                           int32_t ldc, DkdRowMap amap, DkdRowMap bmap, void* stream) {
+                           int32_t ldc, DkdRowMap amap, DkdRowMap bmap, float* a_colsum, void* stream) {
   DKD_CHECK_ARG(A && B && C, "gemm_tn: null operand");
   DKD_CHECK_ARG(M > 0 && N1 > 0 && N2 > 0, "gemm_tn: empty problem");
   DKD_CHECK_ARG(lda % 8 == 0 && ldb % 8 == 0, "gemm_tn: lda=%d / ldb=%d must be multiples of 8", lda, ldb);
@@ -374,7 +562,7 @@ extern "C" int dkd_gemm_tn(const void* A, const void* B, float* C, int32_t M, in
   const int per = cdiv(KT, splits);
   splits = cdiv(KT, per);
   hipLaunchKernelGGL(gemm_tn_kernel, dim3(tiles, splits), dim3(256), 0, as_stream(stream), (const bf16_t*)A, (const bf16_t*)B, C, M,
-                     N1, N2, lda, ldb, ldc, amap, bmap, per);
+                     N1, N2, lda, ldb, ldc, amap, bmap, per, a_colsum);
   DKD_CHECK_LAUNCH("gemm_tn");
   return DKD_OK;
 }

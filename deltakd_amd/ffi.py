@@ -51,7 +51,7 @@ _SIGS = {
     "dkd_device_info": (C.c_int, [C.c_int, C.POINTER(C.c_int), C.c_char_p, C.c_int]),
     "dkd_gemm_nt": (C.c_int, [C.POINTER(Gemm), C.c_void_p]),
     "dkd_gemm_tn": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
-                              C.c_int32, RowMap, RowMap, C.c_void_p]),
+                              C.c_int32, RowMap, RowMap, C.c_void_p, C.c_void_p]),
     "dkd_attn_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "dkd_attn_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
                                C.c_void_p]),

@@ -114,8 +114,7 @@ class _AlignTermFn(torch.autograd.Function):
         align, da = ctx.align, ctx.da
         da.mul_(g.to(da.dtype))
         smap = strip_map(N, npre)
-        ops.gemm_tn(da, ctx.tap2, ensure_grad(align.weight), M=M, N1=Dt, bmap=smap)
-        ops.colsum(da, ensure_grad(align.bias), N=Dt)
+        ops.gemm_tn(da, ctx.tap2, ensure_grad(align.weight), M=M, N1=Dt, bmap=smap, colsum=ensure_grad(align.bias))
         dtap = torch.zeros(B * N, Ds, device=da.device, dtype=BF16)
         ops.gemm_nt(da, ctx.shadow.get(align.weight, transposed=True, pad_k_to=Kp), out=dtap, cmap=smap)
         ctx.da = ctx.tap2 = None

@@ -63,8 +63,7 @@ class _MgdFn(torch.autograd.Function):
         dxt = ops.col2im3x3(dcols, B, hw)
         ds = ops.mask_select_bwd(dxt, mask, ensure_grad(sm.mask_token).view(-1))
         smap = strip_map(N, npre)
-        ops.gemm_tn(ds, tap2, ensure_grad(sm.align.weight), M=M, bmap=smap)
-        ops.colsum(ds, ensure_grad(sm.align.bias))
+        ops.gemm_tn(ds, tap2, ensure_grad(sm.align.weight), M=M, bmap=smap, colsum=ensure_grad(sm.align.bias))
         dtap = torch.zeros(B * N, Ds, device=ds.device, dtype=BF16)
         ops.gemm_nt(ds, sh.get(sm.align.weight, transposed=True), out=dtap, cmap=smap)
         ctx.saved = None
@@ -134,11 +133,9 @@ class _DenoiseFn(torch.autograd.Function):
         B, P, Dt = ctx.dims
         f0, f2 = dn.net[0], dn.net[2]
         dpred.mul_(g.to(BF16))
-        ops.gemm_tn(dpred, h, ensure_grad(f2.weight))
-        ops.colsum(dpred, ensure_grad(f2.bias))
+        ops.gemm_tn(dpred, h, ensure_grad(f2.weight), colsum=ensure_grad(f2.bias))
         dh = ops.gemm_nt(dpred, sh.get(f2.weight, transposed=True), dgelu=True, preact=pre)
-        ops.gemm_tn(dh, x_in, ensure_grad(f0.weight))
-        ops.colsum(dh, ensure_grad(f0.bias))
+        ops.gemm_tn(dh, x_in, ensure_grad(f0.weight), colsum=ensure_grad(f0.bias))
         dx = ops.gemm_nt(dh, sh.get(f0.weight, transposed=True), out_f32=True)
         dtemb = dx.view(B, P, Dt).sum(1)         # the time embedding is broadcast over the P tokens of a sample
         ctx.saved = None

@@ -86,14 +86,15 @@ def gemm_nt(a, b, out=None, *, M=None, bias=None, gelu=False, dgelu=False, relu=
     return out
 
 
-def gemm_tn(a, b, out, *, M=None, N1=None, N2=None, amap=IDENT, bmap=IDENT):
-    """out[N1, N2] (f32) += a[M, N1]^T @ b[M, N2]   (a, b bf16; rows through amap / bmap)."""
+def gemm_tn(a, b, out, *, M=None, N1=None, N2=None, amap=IDENT, bmap=IDENT, colsum=None):
+    """out[N1, N2] (f32) += a[M, N1]^T @ b[M, N2]   (a, b bf16; rows through amap / bmap).
+    ``colsum`` (f32 [N1], optional) += column sums of a: the bias gradient, fused into the same pass."""
     assert a.dtype == BF16 and b.dtype == BF16 and out.dtype == F32
     M = a.shape[0] if M is None else M
     N1 = a.shape[1] if N1 is None else N1
     N2 = b.shape[1] if N2 is None else N2
-    check(lib().dkd_gemm_tn(ptr(a), ptr(b), ptr(out), M, N1, N2, a.stride(0), b.stride(0), out.stride(0), amap, bmap, stream()),
-          "gemm_tn")
+    check(lib().dkd_gemm_tn(ptr(a), ptr(b), ptr(out), M, N1, N2, a.stride(0), b.stride(0), out.stride(0), amap, bmap, ptr(colsum),
+                            stream()), "gemm_tn")
     return out
 
 

@@ -203,22 +203,18 @@ def _block_backward(g, gtap, B, N, blk: Block, sh: Shadow, s1, s2, saved):
     fc1, fc2, proj, qkvl = blk.mlp.fc1, blk.mlp.fc2, blk.attn.proj, blk.attn.qkv
     # ---- MLP branch: x2 = x1 + s2 * (fc2(gelu(fc1(LN2(x1)))));  tap = fc2 output
     dF = ops.scale_cast_bf16(g, rowscale=s2, rows_per_sample=N, add=gtap)
-    ops.gemm_tn(dF, h, ensure_grad(fc2.weight))
-    ops.colsum(dF, ensure_grad(fc2.bias))
+    ops.gemm_tn(dF, h, ensure_grad(fc2.weight), colsum=ensure_grad(fc2.bias))
     dH = ops.gemm_nt(dF, sh.get(fc2.weight, transposed=True), dgelu=True, preact=pre)
-    ops.gemm_tn(dH, y2, ensure_grad(fc1.weight))
-    ops.colsum(dH, ensure_grad(fc1.bias))
+    ops.gemm_tn(dH, y2, ensure_grad(fc1.weight), colsum=ensure_grad(fc1.bias))
     dY2 = ops.gemm_nt(dH, sh.get(fc1.weight, transposed=True))
     ops.layernorm_bwd(dY2, x1, blk.norm2.weight, mean2, rstd2, g, ensure_grad(blk.norm2.weight), ensure_grad(blk.norm2.bias),
                       accumulate=True)
     # ---- attention branch: x1 = x + s1 * proj(attn(qkv(LN1(x))))
     dA = ops.scale_cast_bf16(g, rowscale=s1, rows_per_sample=N)
-    ops.gemm_tn(dA, o, ensure_grad(proj.weight))
-    ops.colsum(dA, ensure_grad(proj.bias))
+    ops.gemm_tn(dA, o, ensure_grad(proj.weight), colsum=ensure_grad(proj.bias))
     dO = ops.gemm_nt(dA, sh.get(proj.weight, transposed=True))
     dqkv = ops.attn_bwd(qkv, o, dO, lse, B, N, H)
-    ops.gemm_tn(dqkv, y1, ensure_grad(qkvl.weight))
-    ops.colsum(dqkv, ensure_grad(qkvl.bias))
+    ops.gemm_tn(dqkv, y1, ensure_grad(qkvl.weight), colsum=ensure_grad(qkvl.bias))
     dY1 = ops.gemm_nt(dqkv, sh.get(qkvl.weight, transposed=True))
     ops.layernorm_bwd(dY1, x, blk.norm1.weight, mean1, rstd1, g, ensure_grad(blk.norm1.weight), ensure_grad(blk.norm1.bias),
                       accumulate=True)
@@ -274,8 +270,7 @@ class _EmbedFn(torch.autograd.Function):
         g = g.contiguous()
         dxb = ops.scale_cast_bf16(g, M=B * P, xmap=strip_map(N, npre))
         w = m.patch_embed.proj.weight
-        ops.gemm_tn(dxb, ctx.patches, ensure_grad(w).view(D, -1))
-        ops.colsum(dxb, ensure_grad(m.patch_embed.proj.bias))
+        ops.gemm_tn(dxb, ctx.patches, ensure_grad(w).view(D, -1), colsum=ensure_grad(m.patch_embed.proj.bias))
         dtok = torch.zeros(npre, D, device=g.device, dtype=F32)
         ops.embed_bwd(g, dtok, ensure_grad(m.pos_embed).view(N, D), B, N, D, npre)
         ensure_grad(m.cls_token).view(-1).add_(dtok[0])
@@ -316,8 +311,7 @@ class _HeadFn(torch.autograd.Function):
                 continue
             dz = torch.zeros(B, Cp, device=x.device, dtype=BF16)
             dz[:, :C] = gz[t]
-            ops.gemm_tn(dz, y, ensure_grad(hd.weight), M=B, N1=C, bmap=RowMap(1, npre, t))
-            ops.colsum(dz, ensure_grad(hd.bias), N=C)
+            ops.gemm_tn(dz, y, ensure_grad(hd.weight), M=B, N1=C, bmap=RowMap(1, npre, t), colsum=ensure_grad(hd.bias))
             # d y[b, t, :] = dz[b, :] @ W  (NT against the K-padded W^T shadow), scattered to row b*npre + t
             ops.gemm_nt(dz, m._shadow.get(hd.weight, transposed=True, pad_k_to=Cp), out=dy, cmap=RowMap(1, npre, t))
         g = torch.zeros_like(x)

@@ -75,9 +75,10 @@ typedef struct {
 int dkd_gemm_nt(const DkdGemm* g, void* stream);
 
 /* C[N1,N2] += sum_m A[m,N1] * B[m,N2]   (weight gradients; f32 atomics into C, row stride ldc).
- * A, B bf16 with row strides lda/ldb and row maps; M is the reduction length. */
+ * A, B bf16 with row strides lda/ldb and row maps; M is the reduction length.
+ * a_colsum (optional, f32 [N1]) += sum_m A[m, :]: the bias gradient, fused (A = dY is already streaming through LDS). */
 int dkd_gemm_tn(const void* A, const void* B, float* C, int32_t M, int32_t N1, int32_t N2, int32_t lda, int32_t ldb,
-                int32_t ldc, DkdRowMap amap, DkdRowMap bmap, void* stream);
+                int32_t ldc, DkdRowMap amap, DkdRowMap bmap, float* a_colsum, void* stream);
 
 /* ---------------------------------------------------------------- attention ([3P] F.scaled_dot_product_attention) */
 /* qkv bf16 [B, N, 3, H, 64] (the fused qkv Linear output, no head-split copy); out bf16 [B, N, H*64];

@@ -106,9 +106,11 @@ def test_gemm_tn(ops, M, N1, N2):
     a[:, :N1] = rnd(M, N1, seed=11).to(BF16)
     b[:, :N2] = rnd(M, N2, seed=12).to(BF16)
     out = torch.full((N1, N2), 0.5, device=dev())
-    ops.gemm_tn(a, b, out, N1=N1, N2=N2)
+    cs = torch.full((N1,), 0.25, device=dev())
+    ops.gemm_tn(a, b, out, N1=N1, N2=N2, colsum=cs)
     ref = 0.5 + a[:, :N1].float().t() @ b[:, :N2].float()
     close(out, ref, 3e-5 * math.sqrt(M), "tn")
+    close(cs, 0.25 + a[:, :N1].float().sum(0), 1e-5 * math.sqrt(M), "tn fused column sums (bias gradient)")
 
 
 def test_gemm_tn_rowmaps(ops):

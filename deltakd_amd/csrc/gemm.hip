@@ -198,6 +198,17 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const DkdGemm g, const 
   const int L = xcd_remap(blockIdx.x, gridDim.x);
   const int m0 = (L / tiles_n) * BM, n0 = (L % tiles_n) * BN;
   const int KT = ABL == 2 ? 0 : g.K / BK;
+  if (ABL == 3) {
+    // dev experiment: de-phase the two workgroups that share a CU so one's epilogue overlaps the other's K loop.
+    // Only the first generation of workgroups can be in lockstep; the one holding the odd wave slot waits ~half a K loop.
+    if (blockIdx.x < 512) {
+      unsigned hw;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+      if (hw & 1) {
+        for (int q = 0; q < g.K / 128; ++q) __builtin_amdgcn_s_sleep(100);
+      }
+    }
+  }
 
   // per-lane source rows for the LDS-DMA staging: 1 KiB chunk = 8 rows x 128 B; lane -> (row = lane>>3, slot = lane&7)
   const bf16_t* arow[4];
@@ -361,6 +372,118 @@ __global__ __launch_bounds__(256, OCC) void gemm_nt_pipe_kernel(const DkdGemm g,
   nt_epilogue<BN, NJ>(g, vec_ok, smem, acc, m0, n0, tid, wr, wc);
 }
 
+// ---- 256 x 256 x 64 tile, 8 waves (2 x 4, 128 x 64 per wave), one workgroup per CU: for the wide teacher GEMMs.
+// The 128^2 kernel moves 1 B of operand from L2 into LDS per 64 FLOP and its K loop is bound by that path (main loop alone:
+// ~950 TF/s, no gain from deeper pipelines: profiles/r01_*); this tile halves the L2->LDS bytes and the LDS-DMA / ds_read
+// instructions per MFMA.
+template <int H>
+__device__ __forceinline__ void epi_pass256(const DkdGemm& g, const int vec_ok, float* cs, f32x4 (&acc)[8][4], const int m0, const int n0,
+                                            const int tid, const int wr, const int wc) {
+  const int lane = tid & 63, frow = lane & 15, fg = lane >> 4;
+  __syncthreads();
+  if (wr == (H >> 1)) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) cs[(i * 16 + fg * 4 + r) * 256 + wc * 64 + j * 16 + frow] = acc[(H & 1) * 4 + i][j][r];
+  }
+  __syncthreads();
+  const int col8 = (tid & 31) * 8, r0 = tid >> 5;      // 32 threads per 256-column row, 16 rows per sweep
+  const int n = n0 + col8;
+  if (n >= g.N) return;
+  EpiIn in[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const int m = m0 + H * 64 + r0 + 16 * s;
+    if (m < g.M) in[s] = epi_prefetch(g, vec_ok, m, n);
+  }
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const int rl = r0 + 16 * s;
+    const int m = m0 + H * 64 + rl;
+    if (m < g.M) {
+      const f32x4 lo = *(const f32x4*)&cs[rl * 256 + col8], hi = *(const f32x4*)&cs[rl * 256 + col8 + 4];
+      epi_finish(g, vec_ok, f32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]}, in[s], m, n);
+    }
+  }
+}
+
+__global__ __launch_bounds__(512, 1) void gemm_nt256_kernel(const DkdGemm g, const int vec_ok) {
+  constexpr int TILE = 256 * 128;      // 32 KiB per operand tile (256 rows x 64 bf16)
+  constexpr int BUF = 2 * TILE;
+  __shared__ __attribute__((aligned(16))) char smem[2 * BUF];   // 128 KiB; the epilogue reuses 64 KiB of it
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = w >> 2, wc = w & 3;
+  const int tiles_n = (g.N + 255) / 256;
+  const int L = xcd_remap(blockIdx.x, gridDim.x);
+  const int m0 = (L / tiles_n) * 256, n0 = (L % tiles_n) * 256;
+  const int KT = g.K / 64;
+
+  const bf16_t* arow[4];
+  const bf16_t* brow[4];
+  int slot[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const int r = w * 32 + c * 8 + (lane >> 3);
+    int m = m0 + r, n = n0 + r;
+    m = m < g.M ? m : g.M - 1;
+    n = n < g.N ? n : g.N - 1;
+    arow[c] = (const bf16_t*)g.A + (size_t)map_row(g.amap, m) * g.lda;
+    brow[c] = (const bf16_t*)g.B + (size_t)n * g.ldb;
+    slot[c] = ((lane & 7) ^ ((r >> 1) & 7)) * 8;
+  }
+  auto stage = [&](int kt) {
+    char* abase = smem + (kt & 1) * BUF;
+    char* bbase = abase + TILE;
+    const int k0 = kt * 64;
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+      __builtin_amdgcn_global_load_lds(GLB_PTR(arow[c] + k0 + slot[c]), LDS_PTR(abase + (w * 32 + c * 8) * 128), 16, 0, 0);
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+      __builtin_amdgcn_global_load_lds(GLB_PTR(brow[c] + k0 + slot[c]), LDS_PTR(bbase + (w * 32 + c * 8) * 128), 16, 0, 0);
+  };
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int frow = lane & 15, fg = lane >> 4, fswz = (frow >> 1) & 7;
+
+  stage(0);
+  for (int kt = 0; kt < KT; ++kt) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (kt + 1 < KT) stage(kt + 1);
+    const char* abase = smem + (kt & 1) * BUF;
+    const char* bbase = abase + TILE;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const int ps = ((kk * 4 + fg) ^ fswz) * 16;
+      bf16x8 a[8], b[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b[j] = *(const bf16x8*)(bbase + (wc * 64 + j * 16 + frow) * 128 + ps);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) a[i] = *(const bf16x8*)(abase + (wr * 128 + i * 16 + frow) * 128 + ps);
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+    }
+  }
+  float* cs = (float*)smem;
+  epi_pass256<0>(g, vec_ok, cs, acc, m0, n0, tid, wr, wc);
+  epi_pass256<1>(g, vec_ok, cs, acc, m0, n0, tid, wr, wc);
+  epi_pass256<2>(g, vec_ok, cs, acc, m0, n0, tid, wr, wc);
+  epi_pass256<3>(g, vec_ok, cs, acc, m0, n0, tid, wr, wc);
+}
+
 // ------------------------------------------------------------------------------------------------ TN (wgrad)
 constexpr int TN_LD = 288;                 // bytes per LDS row (256 B of data + 32 B pad: tr reads conflict-free)
 constexpr int TN_TILE = 64 * TN_LD;        // 18 KiB per operand tile
@@ -520,6 +643,18 @@ extern "C" int dkd_gemm_nt(const DkdGemm* gp, void* stream) {
   const bool narrow = (g.N % 128 != 0) && (g.N % 128 <= 64);
   const int tiles_m = cdiv(g.M, BM);
   static const int variant = getenv("DKD_GEMM_VARIANT") ? atoi(getenv("DKD_GEMM_VARIANT")) : 0;   // dev knob: pipeline shape
+  // wide GEMMs with enough 256^2 tiles to keep 256 CUs balanced (>= 4 rounds): qkv / fc1 of the teacher
+  const bool wide = g.N % 256 == 0 && (long)cdiv(g.M, 256) * (g.N / 256) >= 1024;
+  if ((variant == 0 && wide) || (variant == 6 && g.N % 256 == 0 && g.M >= 256)) {
+    hipLaunchKernelGGL(gemm_nt256_kernel, dim3(cdiv(g.M, 256) * (g.N / 256)), dim3(512), 0, as_stream(stream), g, vec_ok);
+    DKD_CHECK_LAUNCH("gemm_nt256");
+    return DKD_OK;
+  }
+  if (variant == 12 && !narrow) {
+    hipLaunchKernelGGL((gemm_nt_kernel<128, 3>), dim3(tiles_m * cdiv(g.N, 128)), dim3(256), 0, as_stream(stream), g, vec_ok);
+    DKD_CHECK_LAUNCH("gemm_nt stagger");
+    return DKD_OK;
+  }
   if ((variant == 10 || variant == 11) && !narrow) {
     if (variant == 10) hipLaunchKernelGGL((gemm_nt_kernel<128, 1>), dim3(tiles_m * cdiv(g.N, 128)), dim3(256), 0, as_stream(stream), g, vec_ok);
     else hipLaunchKernelGGL((gemm_nt_kernel<128, 2>), dim3(tiles_m * cdiv(g.N, 128)), dim3(256), 0, as_stream(stream), g, vec_ok);

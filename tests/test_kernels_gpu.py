@@ -414,3 +414,24 @@ def test_diffkd_kernels(ops):
     ref2.backward()
     close(loss2, ref2.detach(), 1e-5, "dropout mse")
     close(da, ar.grad, 1e-2, "dropout mse grad (bf16)")
+
+
+def test_gemm_nt_wide_tile_kernel(ops):
+    """Shapes with >= 1024 tiles of 256x256 take the 256^2 kernel (teacher qkv / fc1): all epilogues, ragged M."""
+    M, N, K = 16384 + 37, 4096, 128
+    a = rnd(M, K, seed=130).to(BF16)
+    b = rnd(N, K, scale=0.2, seed=131).to(BF16)
+    bias = rnd(N, seed=132)
+    ref = a.float() @ b.float().t() + bias
+    pre = torch.empty(M, N, device=dev(), dtype=BF16)
+    h = ops.gemm_nt(a, b, bias=bias, gelu=True, preact=pre)
+    close(pre, ref, 1e-2, "wide preact")
+    close(h, torch.nn.functional.gelu(ref), 1e-2, "wide gelu")
+    resid = rnd(M, N, seed=133)
+    sc = (torch.arange(M // 197 + 1, device=dev()) % 3).float()
+    out = ops.gemm_nt(a, b, bias=bias, resid=resid, rowscale=sc, rows_per_sample=197, out_f32=True)
+    close(out, resid + sc.repeat_interleave(197)[:M, None] * ref, 1e-4 * 12, "wide resid f32")
+    dh = ops.gemm_nt(a, b, dgelu=True, preact=pre)
+    x = pre.float().requires_grad_(True)
+    torch.nn.functional.gelu(x).backward(a.float() @ b.float().t())
+    close(dh, x.grad, 1e-2, "wide dgelu")

@@ -167,10 +167,21 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = tmax.item()
 
-    # dominant kernel = the 128x128x64 bf16 MFMA NT GEMM (teacher forward is ~82 % of the step's FLOPs)
-    flops = sum(2.0 * M * N * K for _, M, N, K, _, _ in probe)
-    ms = sum(e0.elapsed_time(e1) for *_, e0, e1 in probe)
+    # dominant kernel = the NT-GEMM symbol with the largest summed duration in the last timed step (teacher forward is
+    # ~82 % of the step's FLOPs); achieved = its algorithmic FLOPs (2 M N K per launch) / its HIP-event time.
+    per = {}
+    for sym, M, N, K, e0, e1 in probe:
+        d = per.setdefault(sym, [0.0, 0.0, 0])
+        d[0] += 2.0 * M * N * K
+        d[1] += e0.elapsed_time(e1)
+        d[2] += 1
+    dom = max(per, key=lambda k: per[k][1]) if per else None
+    flops, ms, launches = per[dom] if dom else (0.0, 0.0, 0)
     achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+    traffic = None
+    tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")     # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this command
+    if dom and os.path.exists(tfile):
+        traffic = json.load(open(tfile)).get(a.config, {}).get(dom)
     f_img = 3 * F_FWD[cfg["student"]] + (F_FWD[cfg["teacher"]] if cfg["distillation_type"] != "none" else 0.0)
     ips = world * a.batch * a.steps / dt
     out = {
@@ -183,8 +194,10 @@ def main():
                    "model_flops_per_image": f_img, "step_mfma_frac_of_2.5PF": ips * f_img / (world * 2.5e15),
                    "train_loss": stats.get("train_loss")},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": 2500.0, "unit": "TFLOP/s", "frac": achieved / 2500.0,
-                     "traffic": None, "kernel": "gemm_nt_kernel (bf16 MFMA NT GEMM, all launches of the last timed step)",
-                     "launches": len(probe), "sum_ms": ms},
+                     "traffic": traffic, "kernel": dom, "launches": launches, "avg_launch_us": ms / max(launches, 1) * 1e3,
+                     "flop_per_launch_avg": flops / max(launches, 1),
+                     "other_gemm_kernels": {k: {"tflops": v[0] / (v[1] * 1e-3) / 1e12, "launches": v[2], "sum_ms": v[1]}
+                                            for k, v in per.items() if k != dom}},
     }
     if rank == 0:
         if world == 1 and not a.no_cpu_baseline:

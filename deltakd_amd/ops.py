@@ -80,7 +80,14 @@ def gemm_nt(a, b, out=None, *, M=None, bias=None, gelu=False, dgelu=False, relu=
         e0.record()
         check(lib().dkd_gemm_nt(C.byref(g), stream()), "gemm_nt")
         e1.record()
-        PROBE.append(("gemm_nt", M, N, K, e0, e1))
+        # same selection rule as dkd_gemm_nt's launcher (csrc/gemm.hip)
+        if N % 256 == 0 and ((M + 255) // 256) * (N // 256) >= 1024:
+            sym = "gemm_nt256_kernel"
+        elif N % 128 != 0 and N % 128 <= 64:
+            sym = "gemm_nt_kernel<64>"
+        else:
+            sym = "gemm_nt_kernel<128>"
+        PROBE.append((sym, M, N, K, e0, e1))
         return out
     check(lib().dkd_gemm_nt(C.byref(g), stream()), "gemm_nt")
     return out

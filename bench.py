@@ -31,10 +31,17 @@ CONFIGS = {
     "mgd": dict(student="deit_tiny_patch16_224", teacher="deit_base_distilled_patch16_224", distillation_type="mgd",
                 alpha=0.5, tau=3.0, mgd_alpha=7e-5, mgd_mask_ratio=0.5),
     "none": dict(student="deit_tiny_patch16_224", teacher="deit_tiny_patch16_224", distillation_type="none", alpha=0.0, tau=1.0),
+    "hard": dict(student="deit_tiny_distilled_patch16_224", teacher="deit_small_distilled_patch16_224",
+                 distillation_type="hard", alpha=0.5, tau=3.0),
+    "diffkd": dict(student="deit_tiny_patch16_224", teacher="deit_base_distilled_patch16_224", distillation_type="diffkd",
+                   alpha=0.1, tau=3.0),
+    "wasskd": dict(student="deit_small_patch16_224", teacher="vit_large_patch16_224", distillation_type="wasskd", alpha=0.1, tau=3.0,
+                   wasskd_type="l1"),
 }
 
-F_FWD = {"deit_tiny_patch16_224": 2.507e9, "deit_tiny_distilled_patch16_224": 2.522e9, "deit_small_distilled_patch16_224": 9.248e9,
-         "deit_base_distilled_patch16_224": 35.314e9}      # SURVEY.md section 8(d), FLOP per image
+F_FWD = {"deit_tiny_patch16_224": 2.507e9, "deit_tiny_distilled_patch16_224": 2.522e9, "deit_small_patch16_224": 9.198e9,
+         "deit_small_distilled_patch16_224": 9.248e9, "deit_base_distilled_patch16_224": 35.314e9,
+         "vit_large_patch16_224": 123.109e9}      # SURVEY.md section 8(d), FLOP per image
 
 
 def make_args(cfg, batch, epochs=1):
@@ -96,10 +103,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    backend = os.environ.get("DKD_DIST_BACKEND", "nccl")        # "gloo": rehearsal of the N > 1 path on a one-GPU box
+    if "DKD_FORCE_DEVICE" in os.environ:
+        local = int(os.environ["DKD_FORCE_DEVICE"])
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", init_method="env://", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", init_method="env://", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend, init_method="env://")
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N > 1"
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
@@ -157,9 +170,8 @@ def main():
     t0 = time.perf_counter()
     if a.steps > 1:
         run(a.steps - 1)
-    ops.PROBE = []                       # last timed step: HIP events around every GEMM launch (roofline.achieved)
+    ops.probe_begin()                    # last timed step: HIP events around every NT-GEMM launch (roofline.achieved)
     stats = run(1)
-    probe, ops.PROBE = ops.PROBE, None
     fence()
     dt = time.perf_counter() - t0
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -169,12 +181,7 @@ def main():
 
     # dominant kernel = the NT-GEMM symbol with the largest summed duration in the last timed step (teacher forward is
     # ~82 % of the step's FLOPs); achieved = its algorithmic FLOPs (2 M N K per launch) / its HIP-event time.
-    per = {}
-    for sym, M, N, K, e0, e1 in probe:
-        d = per.setdefault(sym, [0.0, 0.0, 0])
-        d[0] += 2.0 * M * N * K
-        d[1] += e0.elapsed_time(e1)
-        d[2] += 1
+    per = ops.probe_end()
     dom = max(per, key=lambda k: per[k][1]) if per else None
     flops, ms, launches = per[dom] if dom else (0.0, 0.0, 0)
     achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0

@@ -1,0 +1,81 @@
+// Host-side launch sequences for one transformer block (see include/dkd.h): the library, not Python, walks the kernels.
+#include "common.h"
+
+namespace {
+const DkdRowMap ID = {0, 0, 0};
+
+DkdGemm mk(const void* A, const void* B, void* C, int M, int N, int K) {
+  DkdGemm g = {};
+  g.A = A; g.B = B; g.C = C;
+  g.M = M; g.N = N; g.K = K;
+  g.lda = K; g.ldb = K; g.ldc = N;
+  return g;
+}
+#define TRY(call)            \
+  do {                       \
+    int rc_ = (call);        \
+    if (rc_ != DKD_OK) return rc_; \
+  } while (0)
+
+int block_fwd(const DkdBlock& b, void* st) {
+  const int M = b.B * b.N, D = b.D, Hd = b.hidden;
+  TRY(dkd_layernorm_fwd(b.x, D, ID, b.ln1_w, b.ln1_b, b.y1, b.mean1, b.rstd1, M, D, b.eps, 0, st));
+  DkdGemm g = mk(b.y1, b.qkv_w, b.qkv, M, 3 * D, D);
+  g.epi = DKD_EPI_BIAS; g.bias = b.qkv_b;
+  TRY(dkd_gemm_nt(&g, st));
+  TRY(dkd_attn_fwd(b.qkv, b.o, b.lse, b.B, b.N, b.H, st));
+  g = mk(b.o, b.proj_w, b.x1, M, D, D);
+  g.epi = DKD_EPI_BIAS | DKD_EPI_RESID | DKD_EPI_OUT_F32; g.bias = b.proj_b;
+  g.resid = b.x; g.ldr = D; g.rowscale = b.s1; g.rows_per_sample = b.N;
+  TRY(dkd_gemm_nt(&g, st));
+  TRY(dkd_layernorm_fwd(b.x1, D, ID, b.ln2_w, b.ln2_b, b.y2, b.mean2, b.rstd2, M, D, b.eps, 0, st));
+  g = mk(b.y2, b.fc1_w, b.h, M, Hd, D);
+  g.epi = DKD_EPI_BIAS | DKD_EPI_GELU; g.bias = b.fc1_b; g.preact = b.pre; g.ldp = Hd;
+  TRY(dkd_gemm_nt(&g, st));
+  g = mk(b.h, b.fc2_w, b.x2, M, D, Hd);
+  g.epi = DKD_EPI_BIAS | DKD_EPI_RESID | DKD_EPI_OUT_F32; g.bias = b.fc2_b;
+  g.resid = b.x1; g.ldr = D; g.rowscale = b.s2; g.rows_per_sample = b.N;
+  g.tap = b.tap; g.ldt = D;
+  TRY(dkd_gemm_nt(&g, st));
+  return DKD_OK;
+}
+}  // namespace
+
+extern "C" int dkd_blocks_fwd(const DkdBlock* blocks, int32_t n_blocks, void* stream) {
+  DKD_CHECK_ARG(blocks && n_blocks > 0, "blocks_fwd: no blocks");
+  for (int i = 0; i < n_blocks; ++i) {
+    const DkdBlock& b = blocks[i];
+    DKD_CHECK_ARG(b.x && b.x1 && b.x2 && b.y1 && b.qkv && b.o && b.y2 && b.h, "blocks_fwd: block %d has a null buffer", i);
+    TRY(block_fwd(b, stream));
+  }
+  return DKD_OK;
+}
+
+extern "C" int dkd_block_bwd(const DkdBlock* bp, const DkdBlockGrads* gp, void* st) {
+  DKD_CHECK_ARG(bp && gp, "block_bwd: null descriptor");
+  const DkdBlock& b = *bp;
+  const DkdBlockGrads& r = *gp;
+  DKD_CHECK_ARG(r.g && r.dF && r.dH && r.dqkv && r.dT && b.pre && b.mean1 && b.lse, "block_bwd: missing buffer (was the forward run with saves?)");
+  const int M = b.B * b.N, D = b.D, Hd = b.hidden;
+  // ---- MLP branch
+  TRY(dkd_scale_cast_bf16(r.g, D, ID, b.s2, b.N, r.gtap, 0, D, r.dF, D, M, D, st));
+  TRY(dkd_gemm_tn(r.dF, b.h, r.d_fc2_w, M, D, Hd, D, Hd, Hd, ID, ID, r.d_fc2_b, st));
+  DkdGemm g = mk(r.dF, b.fc2_wt, r.dH, M, Hd, D);
+  g.epi = DKD_EPI_DGELU; g.preact = b.pre; g.ldp = Hd;
+  TRY(dkd_gemm_nt(&g, st));
+  TRY(dkd_gemm_tn(r.dH, b.y2, r.d_fc1_w, M, Hd, D, Hd, D, D, ID, ID, r.d_fc1_b, st));
+  g = mk(r.dH, b.fc1_wt, r.dT, M, D, Hd);
+  TRY(dkd_gemm_nt(&g, st));
+  TRY(dkd_layernorm_bwd(r.dT, 0, b.x1, D, ID, b.ln2_w, b.mean2, b.rstd2, r.g, D, ID, 1, r.d_ln2_w, r.d_ln2_b, M, D, st));
+  // ---- attention branch
+  TRY(dkd_scale_cast_bf16(r.g, D, ID, b.s1, b.N, nullptr, 1, 0, r.dF, D, M, D, st));
+  TRY(dkd_gemm_tn(r.dF, b.o, r.d_proj_w, M, D, D, D, D, D, ID, ID, r.d_proj_b, st));
+  g = mk(r.dF, b.proj_wt, r.dT, M, D, D);
+  TRY(dkd_gemm_nt(&g, st));
+  TRY(dkd_attn_bwd(b.qkv, b.o, r.dT, b.lse, r.dqkv, b.B, b.N, b.H, st));
+  TRY(dkd_gemm_tn(r.dqkv, b.y1, r.d_qkv_w, M, 3 * D, D, 3 * D, D, D, ID, ID, r.d_qkv_b, st));
+  g = mk(r.dqkv, b.qkv_wt, r.dT, M, D, 3 * D);
+  TRY(dkd_gemm_nt(&g, st));
+  TRY(dkd_layernorm_bwd(r.dT, 0, b.x, D, ID, b.ln1_w, b.mean1, b.rstd1, r.g, D, ID, 1, r.d_ln1_w, r.d_ln1_b, M, D, st));
+  return DKD_OK;
+}

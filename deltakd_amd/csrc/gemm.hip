@@ -13,6 +13,8 @@
 //  * epilogue goes through LDS so that bias / GELU / residual / DropPath-scale / feature-tap traffic is 16-B coalesced.
 //  * blockIdx -> tile map is XCD-aware (each XCD's L2 sees a contiguous run of tiles sharing A panels).
 #include <stdlib.h>
+#include <mutex>
+#include <vector>
 #include "common.h"
 
 namespace {
@@ -623,6 +625,69 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const bf16_t* __restric
 
 }  // namespace
 
+// ---- optional launch probe (bench.py): HIP events around every NT-GEMM launch, on the stream it is launched on.
+namespace {
+struct ProbeRec {
+  int sym;
+  double flops;
+  hipEvent_t e0, e1;
+};
+std::mutex g_probe_mu;
+bool g_probe_on = false;
+std::vector<ProbeRec> g_probe;
+struct ProbeScope {
+  bool on;
+  ProbeRec rec;
+  hipStream_t st;
+  ProbeScope(int sym, double flops, hipStream_t s) : on(false), st(s) {
+    std::lock_guard<std::mutex> lk(g_probe_mu);
+    if (!g_probe_on) return;
+    on = true;
+    rec.sym = sym;
+    rec.flops = flops;
+    hipEventCreate(&rec.e0);
+    hipEventCreate(&rec.e1);
+    hipEventRecord(rec.e0, st);
+  }
+  ~ProbeScope() {
+    if (!on) return;
+    hipEventRecord(rec.e1, st);
+    std::lock_guard<std::mutex> lk(g_probe_mu);
+    g_probe.push_back(rec);
+  }
+};
+}  // namespace
+
+extern "C" int dkd_probe_begin(void) {
+  std::lock_guard<std::mutex> lk(g_probe_mu);
+  g_probe.clear();
+  g_probe_on = true;
+  return DKD_OK;
+}
+
+// sym 0 = gemm_nt_kernel<128>, 1 = gemm_nt_kernel<64>, 2 = gemm_nt256_kernel.  Arrays of 3.
+extern "C" int dkd_probe_end(double* flops, double* ms, int32_t* launches) {
+  std::lock_guard<std::mutex> lk(g_probe_mu);
+  g_probe_on = false;
+  for (int i = 0; i < 3; ++i) {
+    flops[i] = 0.0;
+    ms[i] = 0.0;
+    launches[i] = 0;
+  }
+  for (auto& r : g_probe) {
+    hipEventSynchronize(r.e1);
+    float t = 0.f;
+    hipEventElapsedTime(&t, r.e0, r.e1);
+    flops[r.sym] += r.flops;
+    ms[r.sym] += t;
+    launches[r.sym] += 1;
+    hipEventDestroy(r.e0);
+    hipEventDestroy(r.e1);
+  }
+  g_probe.clear();
+  return DKD_OK;
+}
+
 extern "C" int dkd_gemm_nt(const DkdGemm* gp, void* stream) {
   DKD_CHECK_ARG(gp && gp->A && gp->B && gp->C, "gemm_nt: null operand");
   const DkdGemm& g = *gp;
@@ -645,6 +710,7 @@ extern "C" int dkd_gemm_nt(const DkdGemm* gp, void* stream) {
   static const int variant = getenv("DKD_GEMM_VARIANT") ? atoi(getenv("DKD_GEMM_VARIANT")) : 0;   // dev knob: pipeline shape
   // wide GEMMs with enough 256^2 tiles to keep 256 CUs balanced (>= 4 rounds): qkv / fc1 of the teacher
   const bool wide = g.N % 256 == 0 && (long)cdiv(g.M, 256) * (g.N / 256) >= 1024;
+  ProbeScope probe((variant == 0 && wide) ? 2 : (narrow ? 1 : 0), 2.0 * g.M * g.N * g.K, as_stream(stream));
   if ((variant == 0 && wide) || (variant == 6 && g.N % 256 == 0 && g.M >= 256)) {
     hipLaunchKernelGGL(gemm_nt256_kernel, dim3(cdiv(g.M, 256) * (g.N / 256)), dim3(512), 0, as_stream(stream), g, vec_ok);
     DKD_CHECK_LAUNCH("gemm_nt256");

@@ -42,6 +42,20 @@ class Gemm(C.Structure):
     ]
 
 
+class Block(C.Structure):
+    """DkdBlock (include/dkd.h): one transformer block's parameters, shadows and activation buffers."""
+    _fields_ = ([(n, C.c_int32) for n in ("B", "N", "D", "H", "hidden")] + [("eps", C.c_float)] +
+                [(n, C.c_void_p) for n in ("ln1_w", "ln1_b", "ln2_w", "ln2_b", "qkv_b", "proj_b", "fc1_b", "fc2_b",
+                                           "qkv_w", "proj_w", "fc1_w", "fc2_w", "qkv_wt", "proj_wt", "fc1_wt", "fc2_wt",
+                                           "s1", "s2", "x", "x1", "x2", "y1", "qkv", "o", "y2", "pre", "h", "tap",
+                                           "mean1", "rstd1", "mean2", "rstd2", "lse")])
+
+
+class BlockGrads(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("g", "gtap", "d_ln1_w", "d_ln1_b", "d_ln2_w", "d_ln2_b", "d_qkv_w", "d_qkv_b",
+                                          "d_proj_w", "d_proj_b", "d_fc1_w", "d_fc1_b", "d_fc2_w", "d_fc2_b", "dF", "dH", "dqkv", "dT")]
+
+
 _lib = None
 _lock = threading.Lock()
 
@@ -85,6 +99,10 @@ _SIGS = {
                                      C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "dkd_dropout_mse": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_int64,
                                   C.c_void_p]),
+    "dkd_probe_begin": (C.c_int, []),
+    "dkd_probe_end": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int32)]),
+    "dkd_blocks_fwd": (C.c_int, [C.POINTER(Block), C.c_int32, C.c_void_p]),
+    "dkd_block_bwd": (C.c_int, [C.POINTER(Block), C.POINTER(BlockGrads), C.c_void_p]),
     "dkd_jacobi_eigh": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "dkd_adamw_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float,
                                  C.c_float, C.c_float, C.c_float, C.c_int32, C.c_float, C.c_void_p]),
@@ -128,4 +146,5 @@ def ptr(t):
 
 
 def stream():
-    return torch.cuda.current_stream().cuda_stream
+    """Raw hipStream_t of torch's current stream on the current device (the fast accessor: this runs once per launch)."""
+    return torch._C._cuda_getCurrentRawStream(torch.cuda.current_device())

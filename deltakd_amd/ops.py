@@ -12,7 +12,6 @@ from .ffi import (EPI_ACCUM, EPI_BIAS, EPI_DGELU, EPI_GELU, EPI_OUT_F32, EPI_REL
                   check, lib, ptr, stream)
 
 BF16, F32 = torch.bfloat16, torch.float32
-PROBE = None     # list collecting (kernel, M, N, K, start_event, end_event) when bench.py samples kernel durations
 
 
 def _is_f32(t):
@@ -75,20 +74,6 @@ def gemm_nt(a, b, out=None, *, M=None, bias=None, gelu=False, dgelu=False, relu=
     if accumulate:
         epi |= EPI_ACCUM
     g.epi = epi
-    if PROBE is not None:          # bench.py: HIP events around this launch, on the stream it is launched on
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        check(lib().dkd_gemm_nt(C.byref(g), stream()), "gemm_nt")
-        e1.record()
-        # same selection rule as dkd_gemm_nt's launcher (csrc/gemm.hip)
-        if N % 256 == 0 and ((M + 255) // 256) * (N // 256) >= 1024:
-            sym = "gemm_nt256_kernel"
-        elif N % 128 != 0 and N % 128 <= 64:
-            sym = "gemm_nt_kernel<64>"
-        else:
-            sym = "gemm_nt_kernel<128>"
-        PROBE.append((sym, M, N, K, e0, e1))
-        return out
     check(lib().dkd_gemm_nt(C.byref(g), stream()), "gemm_nt")
     return out
 
@@ -315,3 +300,18 @@ def dropout_mse(a, t, keep, keep_scale, loss, w_over_denom):
     da = torch.empty(a.shape, device=a.device, dtype=BF16)
     check(lib().dkd_dropout_mse(ptr(a), ptr(t), ptr(keep), keep_scale, w_over_denom, ptr(loss), ptr(da), a.numel(), stream()), "dropout_mse")
     return da
+
+
+PROBE_SYMBOLS = ("gemm_nt_kernel<128>", "gemm_nt_kernel<64>", "gemm_nt256_kernel")
+
+
+def probe_begin():
+    """bench.py: start bracketing every NT-GEMM launch with HIP events (recorded inside the library, on the launch stream)."""
+    check(lib().dkd_probe_begin(), "probe_begin")
+
+
+def probe_end():
+    """-> {symbol: (flops, ms, launches)} for the launches since probe_begin()."""
+    fl, ms, n = (C.c_double * 3)(), (C.c_double * 3)(), (C.c_int32 * 3)()
+    check(lib().dkd_probe_end(fl, ms, n), "probe_end")
+    return {PROBE_SYMBOLS[i]: (fl[i], ms[i], n[i]) for i in range(3) if n[i]}

@@ -22,7 +22,7 @@ from typing import List, Optional, Sequence
 import torch
 import torch.nn as nn
 
-from . import ops
+from . import ffi, ops
 from .ffi import IDENT, RowMap, strip_map
 
 BF16, F32 = torch.bfloat16, torch.float32
@@ -176,49 +176,123 @@ class Block(nn.Module):
         self.drop_prob = float(drop_path)
 
 
-# ----------------------------------------------------------------------------------------------- block kernels
-def _block_forward(x, B, N, blk: Block, sh: Shadow, s1, s2, save: bool, want_tap: bool, inplace: bool):
-    """x f32 [B*N, D] -> (x2, tap, saved).  s1/s2: per-sample DropPath scale f32 [B] or None."""
-    H = blk.attn.num_heads
+# ----------------------------------------------------------------------------------------------- block execution
+# A block is ONE call into libdkd (dkd_blocks_fwd / dkd_block_bwd, csrc/block.hip): the library walks the kernel launches.
+# Python only allocates the activation slabs (2-3 allocations per block) and fills the descriptor.
+def _bytes_al(n_elems, itemsize):
+    return (n_elems * itemsize + 255) // 256 * 256
+
+
+def _fill_weights(bs: ffi.Block, blk: Block, sh: Shadow, B, N, backward: bool):
+    D = blk.norm1.weight.numel()
+    bs.B, bs.N, bs.D, bs.H, bs.hidden, bs.eps = B, N, D, blk.attn.num_heads, blk.mlp.fc1.out_features, blk.norm1.eps
+    a, m = blk.attn, blk.mlp
+    bs.ln1_w, bs.ln1_b, bs.ln2_w, bs.ln2_b = (blk.norm1.weight.data_ptr(), blk.norm1.bias.data_ptr(), blk.norm2.weight.data_ptr(),
+                                              blk.norm2.bias.data_ptr())
+    bs.qkv_b, bs.proj_b, bs.fc1_b, bs.fc2_b = a.qkv.bias.data_ptr(), a.proj.bias.data_ptr(), m.fc1.bias.data_ptr(), m.fc2.bias.data_ptr()
+    bs.qkv_w, bs.proj_w = sh.get(a.qkv.weight).data_ptr(), sh.get(a.proj.weight).data_ptr()
+    bs.fc1_w, bs.fc2_w = sh.get(m.fc1.weight).data_ptr(), sh.get(m.fc2.weight).data_ptr()
+    if backward:
+        bs.qkv_wt, bs.proj_wt = sh.get(a.qkv.weight, transposed=True).data_ptr(), sh.get(a.proj.weight, transposed=True).data_ptr()
+        bs.fc1_wt, bs.fc2_wt = sh.get(m.fc1.weight, transposed=True).data_ptr(), sh.get(m.fc2.weight, transposed=True).data_ptr()
+
+
+def _block_forward_train(x, B, N, blk: Block, sh: Shadow, s1, s2, want_tap: bool):
+    """x f32 [B*N, D] -> (x2, tap | None, ctx tuple holding the descriptor and the slabs that back its pointers)."""
     M, D = x.shape
-    y1, mean1, rstd1 = ops.layernorm_fwd(x, blk.norm1.weight, blk.norm1.bias, save_stats=save)
-    qkv = ops.gemm_nt(y1, sh.get(blk.attn.qkv.weight), bias=blk.attn.qkv.bias)
-    o, lse = ops.attn_fwd(qkv, B, N, H, need_lse=save)
-    x1 = ops.gemm_nt(o, sh.get(blk.attn.proj.weight), out=x if inplace else None, bias=blk.attn.proj.bias, resid=x, rowscale=s1,
-                     rows_per_sample=N, out_f32=True)
-    y2, mean2, rstd2 = ops.layernorm_fwd(x1, blk.norm2.weight, blk.norm2.bias, save_stats=save)
-    pre = torch.empty(M, blk.mlp.fc1.out_features, device=x.device, dtype=BF16) if save else None
-    h = ops.gemm_nt(y2, sh.get(blk.mlp.fc1.weight), bias=blk.mlp.fc1.bias, gelu=True, preact=pre)
-    tap = torch.empty(M, D, device=x.device, dtype=BF16) if want_tap else None
-    x2 = ops.gemm_nt(h, sh.get(blk.mlp.fc2.weight), out=x1 if inplace else None, bias=blk.mlp.fc2.bias, resid=x1, rowscale=s2,
-                     rows_per_sample=N, tap=tap, out_f32=True)
-    saved = (x, y1, mean1, rstd1, qkv, o, lse, x1, y2, mean2, rstd2, pre, h) if save else None
-    return x2, tap, saved
+    Hd, H = blk.mlp.fc1.out_features, blk.attn.num_heads
+    dev = x.device
+    # bf16 slab: y1 | qkv | o | y2 | pre | h | tap ; f32 slab: x1 | x2 | mean1 | rstd1 | mean2 | rstd2 | lse
+    sizes16 = [M * D, M * 3 * D, M * D, M * D, M * Hd, M * Hd] + ([M * D] if want_tap else [])
+    off16, tot = [], 0
+    for n in sizes16:
+        off16.append(tot)
+        tot += _bytes_al(n, 2)
+    slab16 = torch.empty(tot, device=dev, dtype=torch.uint8)
+    sizes32 = [M * D, M * D, M, M, M, M, B * H * N]
+    off32, tot = [], 0
+    for n in sizes32:
+        off32.append(tot)
+        tot += _bytes_al(n, 4)
+    slab32 = torch.empty(tot, device=dev, dtype=torch.uint8)
+    p16, p32 = slab16.data_ptr(), slab32.data_ptr()
+    bs = ffi.Block()
+    _fill_weights(bs, blk, sh, B, N, backward=False)
+    bs.s1, bs.s2 = ffi.ptr(s1), ffi.ptr(s2)
+    bs.x, bs.x1, bs.x2 = x.data_ptr(), p32 + off32[0], p32 + off32[1]
+    bs.mean1, bs.rstd1, bs.mean2, bs.rstd2, bs.lse = (p32 + off32[i] for i in (2, 3, 4, 5, 6))
+    bs.y1, bs.qkv, bs.o, bs.y2, bs.pre, bs.h = (p16 + off16[i] for i in range(6))
+    tap = None
+    if want_tap:
+        bs.tap = p16 + off16[6]
+        tap = slab16[off16[6]:off16[6] + M * D * 2].view(BF16).view(M, D)
+    ffi.check(ffi.lib().dkd_blocks_fwd(ffi.C.byref(bs), 1, ffi.stream()), "block_fwd")
+    x2 = slab32[off32[1]:off32[1] + M * D * 4].view(F32).view(M, D)
+    return x2, tap, (bs, slab16, slab32, x, s1, s2)
 
 
-def _block_backward(g, gtap, B, N, blk: Block, sh: Shadow, s1, s2, saved):
-    """g: f32 [B*N, D] gradient w.r.t. the block output (modified in place and returned as the input gradient)."""
-    x, y1, mean1, rstd1, qkv, o, lse, x1, y2, mean2, rstd2, pre, h = saved
-    H = blk.attn.num_heads
-    fc1, fc2, proj, qkvl = blk.mlp.fc1, blk.mlp.fc2, blk.attn.proj, blk.attn.qkv
-    # ---- MLP branch: x2 = x1 + s2 * (fc2(gelu(fc1(LN2(x1)))));  tap = fc2 output
-    dF = ops.scale_cast_bf16(g, rowscale=s2, rows_per_sample=N, add=gtap)
-    ops.gemm_tn(dF, h, ensure_grad(fc2.weight), colsum=ensure_grad(fc2.bias))
-    dH = ops.gemm_nt(dF, sh.get(fc2.weight, transposed=True), dgelu=True, preact=pre)
-    ops.gemm_tn(dH, y2, ensure_grad(fc1.weight), colsum=ensure_grad(fc1.bias))
-    dY2 = ops.gemm_nt(dH, sh.get(fc1.weight, transposed=True))
-    ops.layernorm_bwd(dY2, x1, blk.norm2.weight, mean2, rstd2, g, ensure_grad(blk.norm2.weight), ensure_grad(blk.norm2.bias),
-                      accumulate=True)
-    # ---- attention branch: x1 = x + s1 * proj(attn(qkv(LN1(x))))
-    dA = ops.scale_cast_bf16(g, rowscale=s1, rows_per_sample=N)
-    ops.gemm_tn(dA, o, ensure_grad(proj.weight), colsum=ensure_grad(proj.bias))
-    dO = ops.gemm_nt(dA, sh.get(proj.weight, transposed=True))
-    dqkv = ops.attn_bwd(qkv, o, dO, lse, B, N, H)
-    ops.gemm_tn(dqkv, y1, ensure_grad(qkvl.weight), colsum=ensure_grad(qkvl.bias))
-    dY1 = ops.gemm_nt(dqkv, sh.get(qkvl.weight, transposed=True))
-    ops.layernorm_bwd(dY1, x, blk.norm1.weight, mean1, rstd1, g, ensure_grad(blk.norm1.weight), ensure_grad(blk.norm1.bias),
-                      accumulate=True)
+def _backward_workspace(model, M, D, Hd, dev):
+    ws = getattr(model, "_bwd_ws", None)
+    need = _bytes_al(M * D, 2) * 2 + _bytes_al(M * Hd, 2) + _bytes_al(M * 3 * D, 2)
+    if ws is None or ws.numel() < need or ws.device != dev:
+        ws = torch.empty(need, device=dev, dtype=torch.uint8)
+        model._bwd_ws = ws
+    return ws
+
+
+def _block_backward(g, gtap, model, blk: Block, saved):
+    """g: f32 [M, D] gradient w.r.t. the block output (overwritten with the input gradient and returned)."""
+    bs, slab16, slab32, x, s1, s2 = saved
+    M, D, Hd = bs.B * bs.N, bs.D, bs.hidden
+    _fill_weights(bs, blk, model._shadow, bs.B, bs.N, backward=True)
+    ws = _backward_workspace(model, M, D, Hd, g.device)
+    p = ws.data_ptr()
+    gr = ffi.BlockGrads()
+    gr.g, gr.gtap = g.data_ptr(), ffi.ptr(gtap)
+    gr.dF = p
+    gr.dT = p + _bytes_al(M * D, 2)
+    gr.dH = gr.dT + _bytes_al(M * D, 2)
+    gr.dqkv = gr.dH + _bytes_al(M * Hd, 2)
+    a, m = blk.attn, blk.mlp
+    gr.d_ln1_w, gr.d_ln1_b = ensure_grad(blk.norm1.weight).data_ptr(), ensure_grad(blk.norm1.bias).data_ptr()
+    gr.d_ln2_w, gr.d_ln2_b = ensure_grad(blk.norm2.weight).data_ptr(), ensure_grad(blk.norm2.bias).data_ptr()
+    gr.d_qkv_w, gr.d_qkv_b = ensure_grad(a.qkv.weight).data_ptr(), ensure_grad(a.qkv.bias).data_ptr()
+    gr.d_proj_w, gr.d_proj_b = ensure_grad(a.proj.weight).data_ptr(), ensure_grad(a.proj.bias).data_ptr()
+    gr.d_fc1_w, gr.d_fc1_b = ensure_grad(m.fc1.weight).data_ptr(), ensure_grad(m.fc1.bias).data_ptr()
+    gr.d_fc2_w, gr.d_fc2_b = ensure_grad(m.fc2.weight).data_ptr(), ensure_grad(m.fc2.bias).data_ptr()
+    ffi.check(ffi.lib().dkd_block_bwd(ffi.C.byref(bs), ffi.C.byref(gr), ffi.stream()), "block_bwd")
     return g
+
+
+def _blocks_forward_infer(x, B, N, model, scales, want):
+    """Inference pass over all blocks in ONE library call: in-place fp32 residual stream, activation buffers shared by all
+    blocks, taps only for the blocks in ``want``.  Returns (x, taps list)."""
+    blocks = model.blocks
+    depth = len(blocks)
+    M, D = x.shape
+    Hd = blocks[0].mlp.fc1.out_features
+    dev = x.device
+    sizes = [M * D, M * 3 * D, M * D, M * Hd]            # y (LN1 and LN2 outputs alias), qkv, o, h
+    off, tot = [], 0
+    for n in sizes:
+        off.append(tot)
+        tot += _bytes_al(n, 2)
+    slab = torch.empty(tot, device=dev, dtype=torch.uint8)
+    p = slab.data_ptr()
+    arr = (ffi.Block * depth)()
+    taps = [None] * depth
+    for i, blk in enumerate(blocks):
+        bs = arr[i]
+        _fill_weights(bs, blk, model._shadow, B, N, backward=False)
+        bs.s1, bs.s2 = ffi.ptr(scales[2 * i]), ffi.ptr(scales[2 * i + 1])
+        bs.x = bs.x1 = bs.x2 = x.data_ptr()
+        bs.y1 = bs.y2 = p + off[0]
+        bs.qkv, bs.o, bs.h = p + off[1], p + off[2], p + off[3]
+        if i in want:
+            taps[i] = torch.empty(M, D, device=dev, dtype=BF16)
+            bs.tap = taps[i].data_ptr()
+    ffi.check(ffi.lib().dkd_blocks_fwd(arr, depth, ffi.stream()), "blocks_fwd")
+    return x, taps
 
 
 class _BlockFn(torch.autograd.Function):
@@ -226,8 +300,8 @@ class _BlockFn(torch.autograd.Function):
     def forward(ctx, x, model, idx, B, N, s1, s2, want_tap):
         blk = model.blocks[idx]
         ctx.set_materialize_grads(False)     # an unused tap must not cost a zero-filled [M, D] gradient
-        x2, tap, saved = _block_forward(x, B, N, blk, model._shadow, s1, s2, True, want_tap, False)
-        ctx.model, ctx.idx, ctx.B, ctx.N, ctx.s1, ctx.s2 = model, idx, B, N, s1, s2
+        x2, tap, saved = _block_forward_train(x, B, N, blk, model._shadow, s1, s2, want_tap)
+        ctx.model, ctx.idx = model, idx
         ctx.saved = saved
         if tap is None:
             tap = x2.new_empty(0)
@@ -243,12 +317,11 @@ class _BlockFn(torch.autograd.Function):
         if gtap is not None:
             gtap = gtap.contiguous()
         if g is None:
-            g = torch.zeros_like(ctx.saved[0])
+            g = torch.zeros_like(ctx.saved[3])
         g = g.contiguous()
         if g.dtype != F32:
             g = g.float()
-        blk = ctx.model.blocks[ctx.idx]
-        gin = _block_backward(g, gtap, ctx.B, ctx.N, blk, ctx.model._shadow, ctx.s1, ctx.s2, ctx.saved)
+        gin = _block_backward(g, gtap, ctx.model, ctx.model.blocks[ctx.idx], ctx.saved)
         ctx.saved = None
         return gin, None, None, None, None, None, None, None
 
@@ -409,8 +482,8 @@ class VisionTransformer(nn.Module):
                     taps[i] = tap.view(B, N, self.embed_dim)
         else:
             x, _ = self._embed(img)
-            for i, blk in enumerate(self.blocks):
-                x, tap, _ = _block_forward(x, B, N, blk, self._shadow, scales[2 * i], scales[2 * i + 1], False, i in want, True)
+            x, flat_taps = _blocks_forward_infer(x, B, N, self, scales, want)
+            for i, tap in enumerate(flat_taps):
                 if tap is not None:
                     taps[i] = tap.view(B, N, self.embed_dim)
         return x, taps

@@ -154,6 +154,41 @@ int dkd_diffkd_prepare(const void* t, int32_t ldt, DkdRowMap tmap, const float* 
 int dkd_dropout_mse(const float* a, const float* t, const float* keep, float keep_scale, float w_over_denom, float* loss, void* da,
                     int64_t n, void* stream);
 
+/* Launch probe for bench.py: between begin and end every dkd_gemm_nt launch is bracketed by HIP events recorded on ITS stream.
+ * end() synchronises them and returns per kernel symbol (0 = gemm_nt_kernel<128>, 1 = gemm_nt_kernel<64>, 2 = gemm_nt256_kernel)
+ * the algorithmic FLOPs (2 M N K), the summed durations (ms) and the launch counts (arrays of 3).  Off by default. */
+int dkd_probe_begin(void);
+int dkd_probe_end(double* flops, double* ms, int32_t* launches);
+
+/* ---------------------------------------------------------------- transformer block drivers (host-side launch sequences) */
+/* One pre-LN ViT block ([3P] timm Block: x = x + dp(attn(ln1 x)); x = x + dp(mlp(ln2 x))) as ONE call: the library issues the
+ * 7 (forward) / 15 (backward) kernel launches itself, so the Python host pays one FFI crossing per block instead of one per
+ * kernel (the step was host-bound at ~570 launches).  All buffers are caller-owned; M = B*N rows.
+ * Inference: pass mean/rstd/lse/pre = NULL and x1 = x2 = x (in-place residual stream). */
+typedef struct {
+  int32_t B, N, D, H, hidden;
+  float eps;
+  const float *ln1_w, *ln1_b, *ln2_w, *ln2_b, *qkv_b, *proj_b, *fc1_b, *fc2_b;   /* f32 parameters                      */
+  const void *qkv_w, *proj_w, *fc1_w, *fc2_w;                                     /* bf16 [out, in] shadows              */
+  const void *qkv_wt, *proj_wt, *fc1_wt, *fc2_wt;                                 /* bf16 [in, out] shadows (backward)   */
+  const float *s1, *s2;              /* DropPath keep/keep_prob per sample (f32 [B]) or NULL                             */
+  float *x, *x1, *x2;                /* f32 [M, D]: block input, after the attention branch, block output               */
+  void *y1, *qkv, *o, *y2, *pre, *h; /* bf16: LN1 out [M,D], qkv [M,3D], attention out [M,D], LN2 out, fc1 pre-act, GELU out [M,hidden] */
+  void* tap;                         /* bf16 [M, D] feature tap (fc2 output before DropPath/residual) or NULL            */
+  float *mean1, *rstd1, *mean2, *rstd2, *lse;   /* saved statistics (f32 [M] x4, [B,H,N]) or NULL                        */
+} DkdBlock;
+
+typedef struct {
+  float* g;                          /* in: d loss / d x2 (f32 [M, D]); out: d loss / d x (in place)                     */
+  const void* gtap;                  /* bf16 [M, D] gradient of the tap or NULL                                          */
+  float *d_ln1_w, *d_ln1_b, *d_ln2_w, *d_ln2_b, *d_qkv_w, *d_qkv_b, *d_proj_w, *d_proj_b, *d_fc1_w, *d_fc1_b, *d_fc2_w, *d_fc2_b;
+  void *dF, *dH, *dqkv;              /* bf16 workspaces: [M, D] (also reused for dY2, dA, dO, dY1), [M, hidden], [M, 3D]  */
+  void* dT;                          /* bf16 workspace [M, D]                                                            */
+} DkdBlockGrads;
+
+int dkd_blocks_fwd(const DkdBlock* blocks, int32_t n_blocks, void* stream);
+int dkd_block_bwd(const DkdBlock* blk, const DkdBlockGrads* gr, void* stream);
+
 /* ---------------------------------------------------------------- small dense eigensolver (LRKD target, model/loss.py:321) */
 /* Batched cyclic Jacobi: A f32 [batch, n, n] symmetric, n <= 128 -> evals [batch, n] (unsorted), evecs [batch, n, n]
  * (column j pairs with evals[j]).  One workgroup per matrix, LDS-resident; `sweeps` full sweeps (10 converges fp32). */

@@ -4,7 +4,8 @@
 //  gemm_tn : C[N1,N2] += A[M,N1]^T * B[M,N2]   -- every weight gradient (split over M, f32 atomics)
 //
 // Design (MI355X_MICROARCH / cdna_hip_programming sections 3, 5):
-//  * 128 x BN x 64 tiles, 4 waves (2x2), v_mfma_f32_16x16x32_bf16, fp32 accumulators in registers.
+//  * 128 x BN x 64 tiles, 4 waves (2x2) -- and a 256 x 256 x 64 / 8-wave tile for the wide teacher GEMMs --
+//    v_mfma_f32_16x16x32_bf16, fp32 accumulators in registers.
 //  * NT operands are both K-contiguous: tiles go HBM -> LDS with global_load_lds_dwordx4 (LDS-DMA, no VGPR
 //    round trip); the LDS image is lane-linear so the bank-conflict swizzle (16-B slot ^= (row>>1)&7) is applied to the
 //    per-lane SOURCE address and again on the ds_read_b128 fragment reads.
@@ -12,7 +13,6 @@
 //    read with ds_read_b64_tr_b16 (hardware transpose), so no transposed activation copy ever exists in HBM.
 //  * epilogue goes through LDS so that bias / GELU / residual / DropPath-scale / feature-tap traffic is 16-B coalesced.
 //  * blockIdx -> tile map is XCD-aware (each XCD's L2 sees a contiguous run of tiles sharing A panels).
-#include <stdlib.h>
 #include <mutex>
 #include <vector>
 #include "common.h"
@@ -20,7 +20,7 @@
 namespace {
 
 constexpr int BM = 128, BK = 64;
-constexpr int CS_LD = 132;  // f32 epilogue staging row stride (floats)
+constexpr int CS_LD = 132;  // f32 staging row stride (floats) of the wgrad kernel's atomic epilogue
 
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   // bijective "each XCD gets a contiguous chunk" remap (guide T1); bid % 8 labels the XCD group.
@@ -28,10 +28,6 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   const int base = x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q;
   return base + (bid >> 3);
 }
-
-struct EpiCtx {
-  const DkdGemm* g;
-};
 
 __device__ __forceinline__ float epi_scalar(const DkdGemm& g, float v, int m, int n) {
   if (g.epi & DKD_EPI_BIAS) v += g.bias[n];
@@ -184,7 +180,7 @@ __device__ __forceinline__ void nt_epilogue(const DkdGemm& g, const int vec_ok, 
   }
 }
 
-template <int BN, int ABL = 0>   // ABL (dev ablation): 1 = no epilogue, 2 = no main loop
+template <int BN>
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const DkdGemm g, const int vec_ok) {
   constexpr int NJ = BN / 32;             // 16-col MFMA tiles per wave along N
   constexpr int A_BYTES = BM * 128;       // 16 KiB
@@ -199,18 +195,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const DkdGemm g, const 
   const int tiles_n = (g.N + BN - 1) / BN;
   const int L = xcd_remap(blockIdx.x, gridDim.x);
   const int m0 = (L / tiles_n) * BM, n0 = (L % tiles_n) * BN;
-  const int KT = ABL == 2 ? 0 : g.K / BK;
-  if (ABL == 3) {
-    // dev experiment: de-phase the two workgroups that share a CU so one's epilogue overlaps the other's K loop.
-    // Only the first generation of workgroups can be in lockstep; the one holding the odd wave slot waits ~half a K loop.
-    if (blockIdx.x < 512) {
-      unsigned hw;
-      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-      if (hw & 1) {
-        for (int q = 0; q < g.K / 128; ++q) __builtin_amdgcn_s_sleep(100);
-      }
-    }
-  }
+  const int KT = g.K / BK;
 
   // per-lane source rows for the LDS-DMA staging: 1 KiB chunk = 8 rows x 128 B; lane -> (row = lane>>3, slot = lane&7)
   const bf16_t* arow[4];
@@ -255,7 +240,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const DkdGemm g, const 
 
   const int frow = lane & 15, fg = lane >> 4, fswz = (frow >> 1) & 7;
 
-  if (ABL != 2) stage(0, 0);
+  stage(0, 0);
   for (int kt = 0; kt < KT; ++kt) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -277,100 +262,6 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const DkdGemm g, const 
     }
   }
 
-  if (ABL == 1) {      // keep the accumulators live without an epilogue
-    float t = 0.f;
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) t += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
-    if (t == 123456.789f) ((float*)g.C)[tid] = t;
-    return;
-  }
-  nt_epilogue<BN, NJ>(g, vec_ok, smem, acc, m0, n0, tid, wr, wc);
-}
-
-// ---- multi-stage variant: STAGES LDS buffers of 128 x BKP, LDS-DMA prefetch STAGES-1 k-tiles ahead kept in flight
-// across a raw s_barrier with a counted s_waitcnt vmcnt(N) (cdna_hip_programming "Pipelining across barriers").
-template <int BKP, int STAGES, int OCC>
-__global__ __launch_bounds__(256, OCC) void gemm_nt_pipe_kernel(const DkdGemm g, const int vec_ok) {
-  constexpr int BN = 128, NJ = 4;
-  constexpr int ROWB = BKP * 2;                 // bytes per tile row
-  constexpr int SLOTS = BKP / 8;                // 16-B slots per row
-  constexpr int RPC = 1024 / ROWB;              // rows per 1 KiB LDS-DMA chunk
-  constexpr int TILE = 128 * ROWB;              // bytes of one operand tile
-  constexpr int BUF = 2 * TILE;
-  constexpr int CH = 128 / RPC / 4;             // chunks per wave per operand
-  constexpr int GL = 2 * CH;                    // LDS-DMA instructions per wave per stage
-  constexpr int SMEM = (STAGES * BUF) > (128 * BN * 4) ? (STAGES * BUF) : (128 * BN * 4);
-  __shared__ __attribute__((aligned(16))) char smem[SMEM];
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wr = w >> 1, wc = w & 1;
-  const int tiles_n = (g.N + BN - 1) / BN;
-  const int L = xcd_remap(blockIdx.x, gridDim.x);
-  const int m0 = (L / tiles_n) * BM, n0 = (L % tiles_n) * BN;
-  const int KT = g.K / BKP;
-
-  auto swz = [](int row) { return BKP == 64 ? ((row >> 1) & 7) : (((row >> 2) & 1) << 1); };
-
-  const bf16_t* arow[CH];
-  const bf16_t* brow[CH];
-  int slot[CH];
-#pragma unroll
-  for (int c = 0; c < CH; ++c) {
-    const int r = w * 32 + c * RPC + lane / SLOTS;
-    int m = m0 + r, n = n0 + r;
-    m = m < g.M ? m : g.M - 1;
-    n = n < g.N ? n : g.N - 1;
-    arow[c] = (const bf16_t*)g.A + (size_t)map_row(g.amap, m) * g.lda;
-    brow[c] = (const bf16_t*)g.B + (size_t)n * g.ldb;
-    slot[c] = ((lane % SLOTS) ^ swz(r)) * 8;
-  }
-  auto stage = [&](int kt) {
-    char* abase = smem + (kt % STAGES) * BUF;
-    char* bbase = abase + TILE;
-    const int k0 = kt * BKP;
-#pragma unroll
-    for (int c = 0; c < CH; ++c)
-      __builtin_amdgcn_global_load_lds(GLB_PTR(arow[c] + k0 + slot[c]), LDS_PTR(abase + (w * 32 + c * RPC) * ROWB), 16, 0, 0);
-#pragma unroll
-    for (int c = 0; c < CH; ++c)
-      __builtin_amdgcn_global_load_lds(GLB_PTR(brow[c] + k0 + slot[c]), LDS_PTR(bbase + (w * 32 + c * RPC) * ROWB), 16, 0, 0);
-  };
-
-  f32x4 acc[4][NJ];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const int frow = lane & 15, fg = lane >> 4, fswz = swz(frow);
-
-#pragma unroll
-  for (int s = 0; s < STAGES - 1; ++s)
-    if (s < KT) stage(s);
-  for (int kt = 0; kt < KT; ++kt) {
-    // tile kt must have landed; the newer (STAGES-2) tiles may stay in flight
-    if (kt + STAGES - 2 < KT) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * GL) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    if (kt + STAGES - 1 < KT) stage(kt + STAGES - 1);   // overwrites the buffer read in iteration kt-1 (all waves are past it)
-    const char* abase = smem + (kt % STAGES) * BUF;
-    const char* bbase = abase + TILE;
-#pragma unroll
-    for (int kk = 0; kk < BKP / 32; ++kk) {
-      const int ps = ((kk * 4 + fg) ^ fswz) * 16;
-      bf16x8 a[4], b[NJ];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) a[i] = *(const bf16x8*)(abase + (wr * 64 + i * 16 + frow) * ROWB + ps);
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) b[j] = *(const bf16x8*)(bbase + (wc * 64 + j * 16 + frow) * ROWB + ps);
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
-    }
-  }
   nt_epilogue<BN, NJ>(g, vec_ok, smem, acc, m0, n0, tid, wr, wc);
 }
 
@@ -645,13 +536,13 @@ struct ProbeScope {
     on = true;
     rec.sym = sym;
     rec.flops = flops;
-    hipEventCreate(&rec.e0);
-    hipEventCreate(&rec.e1);
-    hipEventRecord(rec.e0, st);
+    (void)hipEventCreate(&rec.e0);
+    (void)hipEventCreate(&rec.e1);
+    (void)hipEventRecord(rec.e0, st);
   }
   ~ProbeScope() {
     if (!on) return;
-    hipEventRecord(rec.e1, st);
+    (void)hipEventRecord(rec.e1, st);
     std::lock_guard<std::mutex> lk(g_probe_mu);
     g_probe.push_back(rec);
   }
@@ -675,14 +566,14 @@ extern "C" int dkd_probe_end(double* flops, double* ms, int32_t* launches) {
     launches[i] = 0;
   }
   for (auto& r : g_probe) {
-    hipEventSynchronize(r.e1);
+    (void)hipEventSynchronize(r.e1);
     float t = 0.f;
-    hipEventElapsedTime(&t, r.e0, r.e1);
+    (void)hipEventElapsedTime(&t, r.e0, r.e1);
     flops[r.sym] += r.flops;
     ms[r.sym] += t;
     launches[r.sym] += 1;
-    hipEventDestroy(r.e0);
-    hipEventDestroy(r.e1);
+    (void)hipEventDestroy(r.e0);
+    (void)hipEventDestroy(r.e1);
   }
   g_probe.clear();
   return DKD_OK;
@@ -707,36 +598,12 @@ extern "C" int dkd_gemm_nt(const DkdGemm* gp, void* stream) {
   if (g.tap) vec_ok = vec_ok && (g.ldt % 8 == 0) && (((uintptr_t)g.tap & 15) == 0);
   const bool narrow = (g.N % 128 != 0) && (g.N % 128 <= 64);
   const int tiles_m = cdiv(g.M, BM);
-  static const int variant = getenv("DKD_GEMM_VARIANT") ? atoi(getenv("DKD_GEMM_VARIANT")) : 0;   // dev knob: pipeline shape
   // wide GEMMs with enough 256^2 tiles to keep 256 CUs balanced (>= 4 rounds): qkv / fc1 of the teacher
   const bool wide = g.N % 256 == 0 && (long)cdiv(g.M, 256) * (g.N / 256) >= 1024;
-  ProbeScope probe((variant == 0 && wide) ? 2 : (narrow ? 1 : 0), 2.0 * g.M * g.N * g.K, as_stream(stream));
-  if ((variant == 0 && wide) || (variant == 6 && g.N % 256 == 0 && g.M >= 256)) {
+  ProbeScope probe(wide ? 2 : (narrow ? 1 : 0), 2.0 * g.M * g.N * g.K, as_stream(stream));
+  if (wide) {
     hipLaunchKernelGGL(gemm_nt256_kernel, dim3(cdiv(g.M, 256) * (g.N / 256)), dim3(512), 0, as_stream(stream), g, vec_ok);
     DKD_CHECK_LAUNCH("gemm_nt256");
-    return DKD_OK;
-  }
-  if (variant == 12 && !narrow) {
-    hipLaunchKernelGGL((gemm_nt_kernel<128, 3>), dim3(tiles_m * cdiv(g.N, 128)), dim3(256), 0, as_stream(stream), g, vec_ok);
-    DKD_CHECK_LAUNCH("gemm_nt stagger");
-    return DKD_OK;
-  }
-  if ((variant == 10 || variant == 11) && !narrow) {
-    if (variant == 10) hipLaunchKernelGGL((gemm_nt_kernel<128, 1>), dim3(tiles_m * cdiv(g.N, 128)), dim3(256), 0, as_stream(stream), g, vec_ok);
-    else hipLaunchKernelGGL((gemm_nt_kernel<128, 2>), dim3(tiles_m * cdiv(g.N, 128)), dim3(256), 0, as_stream(stream), g, vec_ok);
-    DKD_CHECK_LAUNCH("gemm_nt ablation");
-    return DKD_OK;
-  }
-  if (!narrow && variant > 0 && variant < 6) {
-    const dim3 grid(tiles_m * cdiv(g.N, 128));
-    switch (variant) {
-      case 1: hipLaunchKernelGGL((gemm_nt_pipe_kernel<64, 2, 2>), grid, dim3(256), 0, as_stream(stream), g, vec_ok); break;
-      case 2: hipLaunchKernelGGL((gemm_nt_pipe_kernel<32, 3, 3>), grid, dim3(256), 0, as_stream(stream), g, vec_ok); break;
-      case 3: hipLaunchKernelGGL((gemm_nt_pipe_kernel<32, 4, 2>), grid, dim3(256), 0, as_stream(stream), g, vec_ok); break;
-      case 4: hipLaunchKernelGGL((gemm_nt_pipe_kernel<32, 3, 2>), grid, dim3(256), 0, as_stream(stream), g, vec_ok); break;
-      default: hipLaunchKernelGGL((gemm_nt_pipe_kernel<64, 3, 1>), grid, dim3(256), 0, as_stream(stream), g, vec_ok); break;
-    }
-    DKD_CHECK_LAUNCH("gemm_nt");
     return DKD_OK;
   }
   if (narrow) {

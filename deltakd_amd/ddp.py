@@ -33,9 +33,15 @@ class DataParallel(nn.Module):
             shadow = getattr(module, "_shadow", None)
             if shadow is not None:
                 shadow.optimizer_stepped(bf16_fresh=False)
+        self._done = {}
+        self._plan = None
         if optimizer is not None and hasattr(optimizer, "grad_sync"):
             optimizer.grad_sync = self._sync_flat
         self.overlap = overlap and self.world > 1 and optimizer is not None and hasattr(optimizer, "flat_grads")
+        if self.overlap:
+            self._plan = self._plan_overlap()
+            if self._plan:
+                module._grad_ready_hook = self._on_block_backward
 
     # -- forward: same call contract as the wrapped model; ``with_taps`` lets forward_with_features go through the wrapper
     def forward(self, x, with_taps=False):
@@ -51,26 +57,71 @@ class DataParallel(nn.Module):
         n = max(1, self.bucket_bytes // flat.element_size())
         return [flat[i:i + n] for i in range(0, flat.numel(), n)]
 
+    def _reduce(self, t):
+        dist.all_reduce(t, group=self.group)
+        t.div_(self.world)
+
+    def _plan_overlap(self, blocks_per_bucket=4):
+        """Buckets of consecutive transformer blocks, as index ranges of the optimizer's flat gradient buffers.  A bucket is
+        reduced from the block-backward callback as soon as its lowest block has finished (backward walks blocks 11 -> 0)."""
+        blocks = getattr(self.module, "blocks", None)
+        if blocks is None or not hasattr(self._opt, "grad_ranges"):
+            return None
+        plan = {}
+        depth = len(blocks)
+        for lo in range(0, depth, blocks_per_bucket):
+            params = [p for b in list(blocks)[lo:lo + blocks_per_bucket] for p in b.parameters() if p.requires_grad]
+            plan[lo] = self._opt.grad_ranges(params)
+        return plan
+
+    def _on_block_backward(self, idx):
+        rng = self._plan.get(idx)
+        if not rng:
+            return
+        flats = self._opt.flat_grads
+        cur = torch.cuda.current_stream() if flats[0].is_cuda else None
+        if cur is not None:
+            if self._comm_stream is None:
+                self._comm_stream = torch.cuda.Stream()
+            self._comm_stream.wait_stream(cur)          # the gradient kernels of blocks >= idx are enqueued on `cur`
+            with torch.cuda.stream(self._comm_stream):
+                for i, (s, e) in rng.items():
+                    self._reduce(flats[i][s:e])
+        else:
+            for i, (s, e) in rng.items():
+                self._reduce(flats[i][s:e])
+        for i, se in rng.items():
+            self._done.setdefault(i, []).append(se)
+
     def _sync_flat(self, flat_grads):
-        """Called by FusedAdamW.step() before the update: average the flat gradient buffers across ranks."""
+        """Called by FusedAdamW.step() before the update: reduce whatever the backward callbacks have not reduced yet
+        (embedding, head, aux modules -- or everything when overlap is off) and join the comm stream."""
         if self.world == 1:
             return
         cur = torch.cuda.current_stream() if flat_grads[0].is_cuda else None
-        if cur is not None and self.overlap:
+        todo = []
+        for i, fg in enumerate(flat_grads):
+            pos = 0
+            for s, e in sorted(self._done.get(i, [])):
+                if s > pos:
+                    todo.append(fg[pos:s])
+                pos = max(pos, e)
+            if pos < fg.numel():
+                todo.append(fg[pos:])
+        self._done = {}
+        if cur is not None:
             if self._comm_stream is None:
                 self._comm_stream = torch.cuda.Stream()
-            self._comm_stream.wait_stream(cur)          # all gradient kernels enqueued so far
+            self._comm_stream.wait_stream(cur)
             with torch.cuda.stream(self._comm_stream):
-                for fg in flat_grads:
-                    for b in reversed(self._buckets(fg)):   # last layers' gradients are ready first
-                        dist.all_reduce(b, group=self.group)
-                        b.div_(self.world)
+                for t in todo:
+                    for b in self._buckets(t):
+                        self._reduce(b)
             cur.wait_stream(self._comm_stream)
         else:
-            for fg in flat_grads:
-                for b in self._buckets(fg):
-                    dist.all_reduce(b, group=self.group)
-                    b.div_(self.world)
+            for t in todo:
+                for b in self._buckets(t):
+                    self._reduce(b)
 
     def sync_gradients(self):
         """For optimizers without flat storage: coalesce ``p.grad`` into buckets, all-reduce, scatter back."""

@@ -40,6 +40,7 @@ class FusedAdamW(torch.optim.Optimizer):
         super().__init__(params, defaults)
         self._shadows = list(shadows)
         self._flat = []
+        self._where = {}               # id(param) -> (flat index, start, end) inside the flat buffers
         self._step = 0
         self.grad_sync = None          # set by deltakd_amd.ddp: called with the flat grad buffers before the update
         self._flatten()
@@ -69,12 +70,25 @@ class FusedAdamW(torch.optim.Optimizer):
                 if old_grad is not None:
                     p.grad.copy_(old_grad)
                 bound[id(p)] = fb[off:off + k]
+                self._where[id(p)] = (len(self._flat), off, off + n)
                 off += n
             fb.copy_(fp)
             self._flat.append(dict(p=fp, g=fg, bf=fb, m=torch.zeros_like(fp), v=torch.zeros_like(fp)))
         for sh in self._shadows:
             sh.bind_flat(bound)
             sh.optimizer_stepped(bf16_fresh=True)
+
+    def grad_ranges(self, params):
+        """Smallest contiguous [start, end) range of each flat gradient buffer that covers ``params`` -> {flat index: (s, e)}."""
+        out = {}
+        for p in params:
+            w = self._where.get(id(p))
+            if w is None:
+                continue
+            i, s, e = w
+            lo, hi = out.get(i, (s, e))
+            out[i] = (min(lo, s), max(hi, e))
+        return out
 
     @property
     def flat_grads(self):

@@ -323,6 +323,9 @@ class _BlockFn(torch.autograd.Function):
             g = g.float()
         gin = _block_backward(g, gtap, ctx.model, ctx.model.blocks[ctx.idx], ctx.saved)
         ctx.saved = None
+        hook = getattr(ctx.model, "_grad_ready_hook", None)     # data parallel: this block's gradients are final
+        if hook is not None:
+            hook(ctx.idx)
         return gin, None, None, None, None, None, None, None
 
 

@@ -30,6 +30,24 @@ class FlatOpt:
         self.grad_sync(self.flat_grads)
 
 
+class RangedOpt(FlatOpt):
+    """adds FusedAdamW.grad_ranges(): parameter i of block b lives at [64 * (2b + i), +64) of the single flat buffer"""
+
+    def __init__(self, blocks):
+        super().__init__(64 * (2 * len(blocks) + 4))
+        self.where = {id(p): (2 * b + i) * 64 for b, blk in enumerate(blocks) for i, p in enumerate(blk.parameters())}
+
+    def grad_ranges(self, params):
+        offs = [self.where[id(p)] for p in params if id(p) in self.where]
+        return {0: (min(offs), max(offs) + 64)} if offs else {}
+
+
+class Blocky(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.blocks = nn.ModuleList([nn.Linear(4, 4) for _ in range(8)])
+
+
 def _worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -46,9 +64,20 @@ def _worker(rank, world, port, q):
     synced = [p.grad.clone() for p in net.parameters()]
     opt.flat.copy_(torch.arange(1000.) * (rank + 1))
     opt.step()                                    # flat path: buckets of 64 floats
+    # overlapped path: buckets reduced from the block-backward callback (11 -> 0 order), the rest at step()
+    net2 = Blocky()
+    opt2 = RangedOpt(net2.blocks)
+    dp2 = DataParallel(net2, opt2, bucket_bytes=128)
+    assert dp2._plan is not None and sorted(dp2._plan) == [0, 4]
+    opt2.flat.copy_(torch.arange(opt2.flat.numel(), dtype=torch.float32) * (rank + 1))
+    for idx in reversed(range(8)):
+        net2._grad_ready_hook(idx)
+    partial = opt2.flat.clone()                   # block ranges are reduced, the 4 trailing segments are not yet
+    opt2.step()
+    overlap = (partial.tolist(), opt2.flat.tolist())
     gathered = [None] * world
     as_lists = lambda ts: [t.tolist() for t in ts]      # plain lists: no shared-memory handles through the queue
-    dist.all_gather_object(gathered, (as_lists(w0), as_lists(local), as_lists(synced), opt.flat.tolist()))
+    dist.all_gather_object(gathered, (as_lists(w0), as_lists(local), as_lists(synced), opt.flat.tolist(), overlap))
     if rank == 0:
         q.put(gathered)
     dist.destroy_process_group()
@@ -67,7 +96,12 @@ def test_two_rank_gradient_averaging():
         p.join(30)
         assert p.exitcode == 0
     T = torch.tensor
-    (w0a, la, sa, fa), (w0b, lb, sb, fb) = res
+    (w0a, la, sa, fa, ova), (w0b, lb, sb, fb, ovb) = res
+    n = len(ova[1])
+    want = torch.arange(n, dtype=torch.float32) * 1.5
+    assert torch.allclose(T(ova[1]), want) and ova[1] == ovb[1]                       # everything averaged after step()
+    assert torch.allclose(T(ova[0])[:1024], want[:1024])                              # 8 blocks x 2 x 64 reduced during backward
+    assert torch.allclose(T(ova[0])[1024:], torch.arange(1024, n, dtype=torch.float32))   # the tail only at step()
     for a, b in zip(w0a, w0b):
         assert torch.equal(T(a), T(b))            # parameters broadcast from rank 0
     for ga, gb, xa, xb in zip(la, lb, sa, sb):

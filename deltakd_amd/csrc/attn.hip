@@ -67,37 +67,43 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
     bf16x8 qf[2];
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) qf[ks] = *(const bf16x8*)(base + (size_t)qc * ld + ks * 32 + 8 * fg);
+    // Softmax VALU budget (the kernel is VALU-bound, not MFMA-bound): per score one max, one fma (scale folded into the exp2
+    // argument), one exp2, one add; masking touches only the key tiles that straddle or exceed N.
     f32x4 s[NKT];
+    float mx = -INFINITY;
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt) {
       s[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (kt * 16 < N) {                                   // wave-uniform: a key tile entirely past N is never computed
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        const bf16x8 kf = *(const bf16x8*)(Ks + (kt * 16 + i16) * KV_LD + (ks * 32 + 8 * fg) * 2);
-        s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], s[kt], 0, 0, 0);
+        for (int ks = 0; ks < 2; ++ks) {
+          const bf16x8 kf = *(const bf16x8*)(Ks + (kt * 16 + i16) * KV_LD + (ks * 32 + 8 * fg) * 2);
+          s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], s[kt], 0, 0, 0);
+        }
+        if (kt * 16 + 16 > N) {                            // ragged tile: mask keys >= N
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (kt * 16 + 4 * fg + r >= N) s[kt][r] = -INFINITY;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[kt][r]);
       }
     }
-    float mx = -INFINITY;
-#pragma unroll
-    for (int kt = 0; kt < NKT; ++kt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int key = kt * 16 + 4 * fg + r;
-        const float v = key < N ? s[kt][r] * c : -INFINITY;
-        s[kt][r] = v;
-        mx = fmaxf(mx, v);
-      }
     mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float mxc = mx * c;
     float sum = 0.f;
 #pragma unroll
-    for (int kt = 0; kt < NKT; ++kt)
+    for (int kt = 0; kt < NKT; ++kt) {
+      if (kt * 16 < N) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float p = __builtin_amdgcn_exp2f(s[kt][r] - mx);
-        s[kt][r] = p;
-        sum += p;
+        for (int r = 0; r < 4; ++r) {
+          const float p = __builtin_amdgcn_exp2f(fmaf(s[kt][r], c, -mxc));
+          s[kt][r] = p;
+          sum += p;
+        }
       }
+    }
     sum += __shfl_xor(sum, 16, 64);
     sum += __shfl_xor(sum, 32, 64);
 
@@ -118,7 +124,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
       bf16_t* op = out + ((size_t)b * N + q) * D + h * 64 + 4 * fg;
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) store4bf(op + dt * 16, o[dt], inv);
-      if (lse && fg == 0) lse[((size_t)b * H + h) * N + q] = mx * LN2 + __logf(sum);
+      if (lse && fg == 0) lse[((size_t)b * H + h) * N + q] = mxc * LN2 + __logf(sum);
     }
   }
 }
@@ -161,20 +167,25 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
     const float lq = lse[((size_t)b * H + h) * N + qc] * LOG2E;
 
     f32x4 ds[NKT];
+    const float lq3 = lq + 3.f;          // p/8 = exp2(s c - lse log2e - 3): the 1/sqrt(64) of dS rides in the exponent
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt) {
-      f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+      ds[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (kt * 16 < N) {
+        f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        const int off = (kt * 16 + i16) * KV_LD + (ks * 32 + 8 * fg) * 2;
-        s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)(Ks + off), qf[ks], s, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)(Vs + off), dof[ks], dp, 0, 0, 0);
-      }
+        for (int ks = 0; ks < 2; ++ks) {
+          const int off = (kt * 16 + i16) * KV_LD + (ks * 32 + 8 * fg) * 2;
+          s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)(Ks + off), qf[ks], s, 0, 0, 0);
+          dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)(Vs + off), dof[ks], dp, 0, 0, 0);
+        }
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int key = kt * 16 + 4 * fg + r;
-        const float p = key < N ? __builtin_amdgcn_exp2f(s[r] * c - lq) : 0.f;
-        ds[kt][r] = p * (dp[r] - delta) * 0.125f;
+        for (int r = 0; r < 4; ++r) ds[kt][r] = __builtin_amdgcn_exp2f(fmaf(s[r], c, -lq3)) * (dp[r] - delta);
+        if (kt * 16 + 16 > N) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (kt * 16 + 4 * fg + r >= N) ds[kt][r] = 0.f;
+        }
       }
     }
     f32x4 dq[4];
@@ -229,7 +240,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restr
       }
       l = lse[((size_t)b * H + h) * N + tid] * LOG2E;
     }
-    dl_s[tid] = d;
+    dl_s[tid] = d * 0.125f;
     lse_s[tid] = l;
   }
   __syncthreads();
@@ -268,9 +279,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restr
         const f32x4 dl = *(const f32x4*)&dl_s[qt * 16 + 4 * fg];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float p = __builtin_amdgcn_exp2f(s[r] * c - lq[r]);
+          const float p = __builtin_amdgcn_exp2f(fmaf(s[r], c, -lq[r]));
           pp[hf][r] = p;
-          dss[hf][r] = p * (dp[r] - dl[r]) * 0.125f;
+          dss[hf][r] = p * fmaf(dp[r], 0.125f, -dl[r]);
         }
       }
       const bf16x8 pf = pack8(pp[0], pp[1]);

@@ -35,8 +35,9 @@ __device__ __forceinline__ void store4bf(bf16_t* p, const f32x4& v, float s) {
 }
 
 // stage `rows_valid` rows of 64 bf16 (row stride ld elements) into an LDS image of `rows_total` rows, zero padded
+template <int NTHREADS = 256>
 __device__ __forceinline__ void stage_rows(char* dst, const bf16_t* src, int ld, int rows_valid, int rows_total, int tid) {
-  for (int idx = tid; idx < rows_total * 8; idx += 256) {
+  for (int idx = tid; idx < rows_total * 8; idx += NTHREADS) {
     const int row = idx >> 3, ch = idx & 7;
     s16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
     if (row < rows_valid) v = *(const s16x8*)(src + (size_t)row * ld + ch * 8);
@@ -44,8 +45,12 @@ __device__ __forceinline__ void stage_rows(char* dst, const bf16_t* src, int ld,
   }
 }
 
+// 4 waves per (batch, head), two workgroups per CU (LDS: 72 KB each).  Measured alternatives on the teacher shape (3072 heads,
+// N = 198): 8 waves/1 WG per CU 166 us, 8 waves/2 WGs (<= 128 VGPRs: spills) 330 us, this 149 us.  The kernel is latency-bound
+// (Q load -> QK^T -> softmax -> PV -> store per tile), not MFMA-bound.
+constexpr int FWD_WAVES = 4;
 template <int NKT>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
+__global__ __launch_bounds__(64 * FWD_WAVES, 2) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
                                                        float* __restrict__ lse, int N, int H) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -55,13 +60,13 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
   const bf16_t* base = qkv + (size_t)b * N * ld + h * 64;
   char* Ks = smem;
   char* Vs = smem + NKT * 16 * KV_LD;
-  stage_rows(Ks, base + D, ld, N, NKT * 16, tid);
-  stage_rows(Vs, base + 2 * D, ld, N, NKT * 16, tid);
+  stage_rows<64 * FWD_WAVES>(Ks, base + D, ld, N, NKT * 16, tid);
+  stage_rows<64 * FWD_WAVES>(Vs, base + 2 * D, ld, N, NKT * 16, tid);
   __syncthreads();
 
   const float c = 0.125f * LOG2E;
   const int nqt = (N + 15) >> 4;
-  for (int qt = w; qt < nqt; qt += 4) {
+  for (int qt = w; qt < nqt; qt += FWD_WAVES) {
     const int q = qt * 16 + i16;
     const int qc = q < N ? q : N - 1;
     bf16x8 qf[2];
@@ -70,40 +75,38 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
     // Softmax VALU budget (the kernel is VALU-bound, not MFMA-bound): per score one max, one fma (scale folded into the exp2
     // argument), one exp2, one add; masking touches only the key tiles that straddle or exceed N.
     f32x4 s[NKT];
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {                     // all QK^T MFMAs back to back (no VALU consumer in between)
+      s[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const bf16x8 kf = *(const bf16x8*)(Ks + (kt * 16 + i16) * KV_LD + (ks * 32 + 8 * fg) * 2);
+        s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], s[kt], 0, 0, 0);
+      }
+    }
     float mx = -INFINITY;
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt) {
-      s[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (kt * 16 < N) {                                   // wave-uniform: a key tile entirely past N is never computed
+      if (kt * 16 + 16 > N) {                              // wave-uniform: only the ragged / padded key tiles are masked
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-          const bf16x8 kf = *(const bf16x8*)(Ks + (kt * 16 + i16) * KV_LD + (ks * 32 + 8 * fg) * 2);
-          s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], s[kt], 0, 0, 0);
-        }
-        if (kt * 16 + 16 > N) {                            // ragged tile: mask keys >= N
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-            if (kt * 16 + 4 * fg + r >= N) s[kt][r] = -INFINITY;
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[kt][r]);
+        for (int r = 0; r < 4; ++r)
+          if (kt * 16 + 4 * fg + r >= N) s[kt][r] = -INFINITY;
       }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[kt][r]);
     }
     mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     const float mxc = mx * c;
     float sum = 0.f;
 #pragma unroll
-    for (int kt = 0; kt < NKT; ++kt) {
-      if (kt * 16 < N) {
+    for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float p = __builtin_amdgcn_exp2f(fmaf(s[kt][r], c, -mxc));
-          s[kt][r] = p;
-          sum += p;
-        }
+      for (int r = 0; r < 4; ++r) {
+        const float p = __builtin_amdgcn_exp2f(fmaf(s[kt][r], c, -mxc));
+        s[kt][r] = p;
+        sum += p;
       }
-    }
     sum += __shfl_xor(sum, 16, 64);
     sum += __shfl_xor(sum, 32, 64);
 
@@ -131,7 +134,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
 
 // dQ: waves own query tiles; K (row + transposed reads) and V (row reads) in LDS.
 template <int NKT>
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out,
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out,
                                                           const bf16_t* __restrict__ dout, const float* __restrict__ lse,
                                                           bf16_t* __restrict__ dqkv, int N, int H) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -210,7 +213,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
 
 // dK, dV: waves own key tiles; Q and dO (row + transposed reads), lse and delta in LDS.
 template <int NQT>
-__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out,
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out,
                                                            const bf16_t* __restrict__ dout, const float* __restrict__ lse,
                                                            bf16_t* __restrict__ dqkv, int N, int H) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -341,7 +344,7 @@ extern "C" int dkd_attn_fwd(const void* qkv, void* out, float* lse, int32_t B, i
   const int smem = 2 * nt * 16 * KV_LD;
   DISPATCH_NT(nt, {
     if (int rc = set_smem(attn_fwd_kernel<T>, smem)) return rc;
-    hipLaunchKernelGGL(attn_fwd_kernel<T>, dim3(B * H), dim3(256), smem, as_stream(stream), (const bf16_t*)qkv, (bf16_t*)out, lse, N, H);
+    hipLaunchKernelGGL(attn_fwd_kernel<T>, dim3(B * H), dim3(64 * FWD_WAVES), smem, as_stream(stream), (const bf16_t*)qkv, (bf16_t*)out, lse, N, H);
   });
   DKD_CHECK_LAUNCH("attn_fwd");
   return DKD_OK;

@@ -1,33 +1,51 @@
-// LayerNorm forward / backward (HBM-bound; one wave per row, 16-B accesses).
+// LayerNorm forward / backward (HBM-bound; 16-B accesses).
 // Replaces nn.LayerNorm(eps=1e-6) inside timm's Block ([3P], reached from model/models.py:195 of the reference).
+//
+// A row is owned by LPR lanes: 64 (one row per wave, D <= 1024) or, for narrow models (D <= 256: DeiT-tiny's 192), 16 lanes so
+// that a wave works on 4 rows at once -- with one row per wave a 192-wide row keeps 48 lanes busy with a single float4 each
+// and the two dependent wave reductions per row dominate (the backward ran at half of its HBM bound).
 #include "common.h"
 
 namespace {
 
-constexpr int MAXV = 4;  // float4 vectors per lane: D <= 64 * 4 * MAXV = 1024
+constexpr int MAXV = 4;  // float4 vectors per lane: D <= LPR * 4 * MAXV
 
-template <bool OUT_F32>
+template <int LPR>
+__device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+  for (int o = LPR / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+__device__ __forceinline__ f32x4 load_dy(const void* dy, bool f32, size_t off) {
+  if (f32) return *(const f32x4*)((const float*)dy + off);
+  const uint2 pk = *(const uint2*)((const bf16_t*)dy + off);
+  return f32x4{__uint_as_float(pk.x << 16), __uint_as_float(pk.x & 0xffff0000u), __uint_as_float(pk.y << 16), __uint_as_float(pk.y & 0xffff0000u)};
+}
+
+template <bool OUT_F32, int LPR>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, int ldx, DkdRowMap xmap, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, void* __restrict__ y, float* __restrict__ mean,
                                                      float* __restrict__ rstd, int M, int D, float eps) {
-  const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= M) return;
-  const float* xr = x + (size_t)map_row(xmap, row) * ldx;
+  constexpr int RPW = 64 / LPR;
+  const int lane = threadIdx.x & 63, sl = lane % LPR, gq = lane / LPR;
+  const int row = (blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW + gq;
+  const bool live = row < M;
+  const float* xr = x + (size_t)map_row(xmap, live ? row : 0) * ldx;
   const int nv = D >> 2;
   f32x4 v[MAXV];
   float s = 0.f;
 #pragma unroll
   for (int i = 0; i < MAXV; ++i) {
-    const int c = lane + 64 * i;
-    v[i] = c < nv ? *(const f32x4*)(xr + 4 * c) : f32x4{0.f, 0.f, 0.f, 0.f};
+    const int c = sl + LPR * i;
+    v[i] = (live && c < nv) ? *(const f32x4*)(xr + 4 * c) : f32x4{0.f, 0.f, 0.f, 0.f};
     s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
   }
-  const float mu = wave_sum(s) / D;
+  const float mu = group_sum<LPR>(s) / D;
   float q = 0.f;
 #pragma unroll
   for (int i = 0; i < MAXV; ++i) {
-    const int c = lane + 64 * i;
+    const int c = sl + LPR * i;
     if (c < nv) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -36,14 +54,15 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
       }
     }
   }
-  const float rs = rsqrtf(wave_sum(q) / D + eps);
-  if (lane == 0) {
+  const float rs = rsqrtf(group_sum<LPR>(q) / D + eps);
+  if (!live) return;
+  if (sl == 0) {
     if (mean) mean[row] = mu;
     if (rstd) rstd[row] = rs;
   }
 #pragma unroll
   for (int i = 0; i < MAXV; ++i) {
-    const int c = lane + 64 * i;
+    const int c = sl + LPR * i;
     if (c < nv) {
       const f32x4 g = *(const f32x4*)(gamma + 4 * c), bb = *(const f32x4*)(beta + 4 * c);
       f32x4 o;
@@ -58,47 +77,42 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
   }
 }
 
-// Each block walks ROWS_PER_BLOCK rows (4 waves x rows), keeps per-column dgamma/dbeta partials in registers, combines the
-// 4 waves through LDS and issues one f32 atomic per column per block.
+// Each block walks LNB_ROWS rows, keeps per-column dgamma/dbeta partials in registers, combines them through LDS and issues one
+// f32 atomic per column per block.
 constexpr int LNB_ROWS = 64;
-template <bool DY_F32>
+template <bool DY_F32, int LPR>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy, const float* __restrict__ x, int ldx, DkdRowMap xmap,
                                                      const float* __restrict__ gamma, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, float* __restrict__ dx, int lddx, DkdRowMap dxmap,
                                                      int accumulate, float* __restrict__ dgamma, float* __restrict__ dbeta, int M, int D) {
-  __shared__ float red[2][4][1024];
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  constexpr int RPW = 64 / LPR;
+  __shared__ float red[2][4][LPR * 4 * MAXV];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, sl = lane % LPR, gq = lane / LPR;
   const int nv = D >> 2;
   f32x4 g[MAXV], ag[MAXV], ab[MAXV];
 #pragma unroll
   for (int i = 0; i < MAXV; ++i) {
-    const int c = lane + 64 * i;
+    const int c = sl + LPR * i;
     g[i] = c < nv ? *(const f32x4*)(gamma + 4 * c) : f32x4{0.f, 0.f, 0.f, 0.f};
     ag[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     ab[i] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
   const int r0 = blockIdx.x * LNB_ROWS;
-  for (int rr = w; rr < LNB_ROWS; rr += 4) {
-    const int row = r0 + rr;
-    if (row >= M) break;
-    const float* xr = x + (size_t)map_row(xmap, row) * ldx;
-    const float mu = mean[row], rs = rstd[row];
+  for (int rr = w * RPW; rr < LNB_ROWS; rr += 4 * RPW) {
+    const int row = r0 + rr + gq;
+    const bool live = row < M;          // lanes of a dead row still take part in the group shuffles
+    const float* xr = x + (size_t)map_row(xmap, live ? row : 0) * ldx;
+    const float mu = live ? mean[row] : 0.f, rs = live ? rstd[row] : 0.f;
     f32x4 xh[MAXV], gy[MAXV];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
-      const int c = lane + 64 * i;
+      const int c = sl + LPR * i;
       xh[i] = f32x4{0.f, 0.f, 0.f, 0.f};
       gy[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (c < nv) {
+      if (live && c < nv) {
         const f32x4 xv = *(const f32x4*)(xr + 4 * c);
-        f32x4 d;
-        if (DY_F32) d = *(const f32x4*)((const float*)dy + (size_t)row * D + 4 * c);
-        else {
-          const uint2 pk = *(const uint2*)((const bf16_t*)dy + (size_t)row * D + 4 * c);
-          d = f32x4{__uint_as_float(pk.x << 16), __uint_as_float(pk.x & 0xffff0000u), __uint_as_float(pk.y << 16),
-                    __uint_as_float(pk.y & 0xffff0000u)};
-        }
+        const f32x4 d = load_dy(dy, DY_F32, (size_t)row * D + 4 * c);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           xh[i][e] = (xv[e] - mu) * rs;
@@ -110,27 +124,41 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
         }
       }
     }
-    s1 = wave_sum(s1) / D;
-    s2 = wave_sum(s2) / D;
-    float* dr = dx + (size_t)map_row(dxmap, row) * lddx;
+    s1 = group_sum<LPR>(s1) / D;
+    s2 = group_sum<LPR>(s2) / D;
+    if (live) {
+      float* dr = dx + (size_t)map_row(dxmap, row) * lddx;
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
-      const int c = lane + 64 * i;
-      if (c < nv) {
-        f32x4 o;
+      for (int i = 0; i < MAXV; ++i) {
+        const int c = sl + LPR * i;
+        if (c < nv) {
+          f32x4 o;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = rs * (gy[i][e] - s1 - xh[i][e] * s2);
-        if (accumulate) o += *(const f32x4*)(dr + 4 * c);
-        *(f32x4*)(dr + 4 * c) = o;
+          for (int e = 0; e < 4; ++e) o[e] = rs * (gy[i][e] - s1 - xh[i][e] * s2);
+          if (accumulate) o += *(const f32x4*)(dr + 4 * c);
+          *(f32x4*)(dr + 4 * c) = o;
+        }
       }
     }
   }
+  // combine the RPW row groups of a wave (lanes sl, sl+LPR, ...), then the 4 waves through LDS
 #pragma unroll
-  for (int i = 0; i < MAXV; ++i) {
-    const int c = lane + 64 * i;
-    if (c < nv) {
-      *(f32x4*)&red[0][w][4 * c] = ag[i];
-      *(f32x4*)&red[1][w][4 * c] = ab[i];
+  for (int i = 0; i < MAXV; ++i)
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int o = LPR; o < 64; o <<= 1) {
+        ag[i][e] += __shfl_xor(ag[i][e], o, 64);
+        ab[i][e] += __shfl_xor(ab[i][e], o, 64);
+      }
+  if (gq == 0) {
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      const int c = sl + LPR * i;
+      if (c < nv) {
+        *(f32x4*)&red[0][w][4 * c] = ag[i];
+        *(f32x4*)&red[1][w][4 * c] = ab[i];
+      }
     }
   }
   __syncthreads();
@@ -146,10 +174,16 @@ extern "C" int dkd_layernorm_fwd(const float* x, int32_t ldx, DkdRowMap xmap, co
                                  float* mean, float* rstd, int32_t M, int32_t D, float eps, int32_t y_is_f32, void* stream) {
   DKD_CHECK_ARG(x && gamma && beta && y, "layernorm_fwd: null operand");
   DKD_CHECK_ARG(M > 0 && D > 0 && D % 4 == 0 && D <= 1024 && ldx % 4 == 0, "layernorm_fwd: need D %% 4 == 0, D <= 1024 (D=%d ldx=%d)", D, ldx);
-  if (y_is_f32)
-    hipLaunchKernelGGL(ln_fwd_kernel<true>, dim3(cdiv(M, 4)), dim3(256), 0, as_stream(stream), x, ldx, xmap, gamma, beta, y, mean, rstd, M, D, eps);
-  else
-    hipLaunchKernelGGL(ln_fwd_kernel<false>, dim3(cdiv(M, 4)), dim3(256), 0, as_stream(stream), x, ldx, xmap, gamma, beta, y, mean, rstd, M, D, eps);
+  hipStream_t st = as_stream(stream);
+  if (D <= 256) {
+    const dim3 grid(cdiv(M, 16));
+    if (y_is_f32) hipLaunchKernelGGL((ln_fwd_kernel<true, 16>), grid, dim3(256), 0, st, x, ldx, xmap, gamma, beta, y, mean, rstd, M, D, eps);
+    else hipLaunchKernelGGL((ln_fwd_kernel<false, 16>), grid, dim3(256), 0, st, x, ldx, xmap, gamma, beta, y, mean, rstd, M, D, eps);
+  } else {
+    const dim3 grid(cdiv(M, 4));
+    if (y_is_f32) hipLaunchKernelGGL((ln_fwd_kernel<true, 64>), grid, dim3(256), 0, st, x, ldx, xmap, gamma, beta, y, mean, rstd, M, D, eps);
+    else hipLaunchKernelGGL((ln_fwd_kernel<false, 64>), grid, dim3(256), 0, st, x, ldx, xmap, gamma, beta, y, mean, rstd, M, D, eps);
+  }
   DKD_CHECK_LAUNCH("layernorm_fwd");
   return DKD_OK;
 }
@@ -159,12 +193,17 @@ extern "C" int dkd_layernorm_bwd(const void* dy, int32_t dy_is_f32, const float*
                                  float* dgamma, float* dbeta, int32_t M, int32_t D, void* stream) {
   DKD_CHECK_ARG(dy && x && gamma && mean && rstd && dx && dgamma && dbeta, "layernorm_bwd: null operand");
   DKD_CHECK_ARG(M > 0 && D > 0 && D % 4 == 0 && D <= 1024 && ldx % 4 == 0 && lddx % 4 == 0, "layernorm_bwd: bad D=%d", D);
-  if (dy_is_f32)
-    hipLaunchKernelGGL(ln_bwd_kernel<true>, dim3(cdiv(M, LNB_ROWS)), dim3(256), 0, as_stream(stream), dy, x, ldx, xmap, gamma, mean, rstd, dx,
-                       lddx, dxmap, accumulate, dgamma, dbeta, M, D);
-  else
-    hipLaunchKernelGGL(ln_bwd_kernel<false>, dim3(cdiv(M, LNB_ROWS)), dim3(256), 0, as_stream(stream), dy, x, ldx, xmap, gamma, mean, rstd, dx,
-                       lddx, dxmap, accumulate, dgamma, dbeta, M, D);
+  hipStream_t st = as_stream(stream);
+  const dim3 grid(cdiv(M, LNB_ROWS));
+#define LNB_ARGS dy, x, ldx, xmap, gamma, mean, rstd, dx, lddx, dxmap, accumulate, dgamma, dbeta, M, D
+  if (D <= 256) {
+    if (dy_is_f32) hipLaunchKernelGGL((ln_bwd_kernel<true, 16>), grid, dim3(256), 0, st, LNB_ARGS);
+    else hipLaunchKernelGGL((ln_bwd_kernel<false, 16>), grid, dim3(256), 0, st, LNB_ARGS);
+  } else {
+    if (dy_is_f32) hipLaunchKernelGGL((ln_bwd_kernel<true, 64>), grid, dim3(256), 0, st, LNB_ARGS);
+    else hipLaunchKernelGGL((ln_bwd_kernel<false, 64>), grid, dim3(256), 0, st, LNB_ARGS);
+  }
+#undef LNB_ARGS
   DKD_CHECK_LAUNCH("layernorm_bwd");
   return DKD_OK;
 }

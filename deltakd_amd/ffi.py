@@ -10,7 +10,7 @@ import threading
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libdkd.so")
+LIB_PATH = os.environ.get("DKD_LIB") or os.path.join(_HERE, "lib", "libdkd.so")     # DKD_LIB: A/B another build of the same ABI
 
 EPI_BIAS, EPI_GELU, EPI_DGELU, EPI_RESID = 1, 2, 4, 8
 EPI_OUT_F32, EPI_TAP_F32, EPI_RELU, EPI_ACCUM = 16, 32, 64, 128

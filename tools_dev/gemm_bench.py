@@ -37,8 +37,32 @@ for name, M, N, K, epi in shapes:
     res[name] = (ms * 1e3, tf)
     print(f"{name:8s} M={M} N={N} K={K} {epi:6s} {ms*1e3:8.1f} us  {tf:7.1f} TFLOP/s", flush=True)
 # correctness spot check of the last shape
-ref = a[:512].float() @ b.float().t() + bias
-if epi == "resid":
-    ref = ref + kw["resid"][:512]
-err = (out[:512].float() - ref).abs().max().item() / ref.abs().max().item()
-print("spot-check rel err", err)
+if not res:
+    epi = None
+ref = (a[:512].float() @ b.float().t() + bias) if res else None
+if res:
+    if epi == "resid":
+        ref = ref + kw["resid"][:512]
+    err = (out[:512].float() - ref).abs().max().item() / ref.abs().max().item()
+    print("spot-check rel err", err)
+
+print("-- wgrad (gemm_tn) on the student shapes")
+for name, M, N1, N2 in (("s_fc2_w", 50432, 192, 768), ("s_fc1_w", 50432, 768, 192), ("s_proj_w", 50432, 192, 192), ("s_qkv_w", 50432, 576, 192),
+                        ("gram", 50176, 768, 768)):
+    if only and name not in only: continue
+    a = torch.randn(M, N1, device=dev).to(BF16)
+    b = torch.randn(M, N2, device=dev).to(BF16)
+    out = torch.zeros(N1, N2, device=dev)
+    cs = torch.zeros(N1, device=dev)
+    ops.gemm_tn(a, b, out, colsum=cs)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        ops.gemm_tn(a, b, out, colsum=cs)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    print(f"{name:9s} M={M} N1={N1} N2={N2} {ms*1e3:8.1f} us  {2.0*M*N1*N2/ms/1e9:7.1f} TFLOP/s  {(M*(N1+N2)*2)/ms/1e6:7.1f} GB/s min-traffic", flush=True)
+ref = a.float().t() @ b.float()
+print("tn spot-check rel err", ((out / (reps + 1)) - ref).abs().max().item() / ref.abs().max().item())

@@ -514,6 +514,175 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const bf16_t* __restric
   }
 }
 
+// ---- wgrad tile 128 x 192 for the narrow student (D = 192): the 192-wide operand is covered by ONE tile, so the wide operand
+// (dY or the saved activation, 4x larger) streams through exactly once instead of once per 128-column tile (the 128^2 kernel
+// runs at ~3.6 TB/s of re-read traffic: fabric-bound, not MFMA-bound).  SWAP: the caller's A is the 192-wide one; the kernel
+// then computes (B^T A) and writes it transposed, and the fused bias column sums come from the kernel's B operand.
+constexpr int T192_LDB = 416;              // 384 B of data + 32 B pad (tr reads conflict-free: 104 dwords = 40 mod 64)
+constexpr int T192_CS = 197;               // odd f32 staging stride: row- and column-order reads both conflict-free
+template <bool SWAP>
+__global__ __launch_bounds__(256, 2) void gemm_tn192_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, float* C, int M,
+                                                            int N1, int N2, int lda, int ldb, int ldc, DkdRowMap amap, DkdRowMap bmap,
+                                                            int kt_per_split, float* __restrict__ colsum) {
+  constexpr int A_BYTES = 64 * TN_LD, B_BYTES = 64 * T192_LDB;
+  constexpr int SMEM = (A_BYTES + B_BYTES) > (64 * T192_CS * 4) ? (A_BYTES + B_BYTES) : (64 * T192_CS * 4);
+  __shared__ __attribute__((aligned(16))) char smem[SMEM];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = w >> 1, wc = w & 1;
+  const int n1_0 = blockIdx.x * 128;
+  const int KT_all = (M + 63) / 64;
+  const int kt_begin = blockIdx.y * kt_per_split;
+  const int kt_end = min(KT_all, kt_begin + kt_per_split);
+  if (kt_begin >= kt_end) return;
+
+  const int arow = tid >> 4, acol = (tid & 15) * 8;          // A staging: rows arow + 16 c (c < 4)
+  const int brow = tid / 24, bcol = (tid % 24) * 8;          // B staging: threads 0..239, rows brow + 10 c (c < 7)
+  const bool bld = tid < 240;
+  s16x8 ra[4], rb[7];
+  const bool sum_a = colsum != nullptr && !SWAP, sum_b = colsum != nullptr && SWAP && blockIdx.x == 0;
+  float csum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  auto gload = [&](int kt) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int m = kt * 64 + arow + 16 * c;
+      s16x8 va = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (m < M) {
+        const bf16_t* pa = A + (size_t)map_row(amap, m) * lda + n1_0 + acol;
+        if (n1_0 + acol + 8 <= N1) va = *(const s16x8*)pa;
+        else
+          for (int e = 0; e < 8; ++e)
+            if (n1_0 + acol + e < N1) va[e] = (short)pa[e];
+      }
+      ra[c] = va;
+      if (sum_a) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) csum[e] += __uint_as_float(((uint32_t)(uint16_t)va[e]) << 16);
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < 7; ++c) {
+      const int r = brow + 10 * c;
+      const int m = kt * 64 + r;
+      s16x8 vb = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (bld && r < 64 && m < M) {
+        const bf16_t* pb = B + (size_t)map_row(bmap, m) * ldb + bcol;
+        if (bcol + 8 <= N2) vb = *(const s16x8*)pb;
+        else
+          for (int e = 0; e < 8; ++e)
+            if (bcol + e < N2) vb[e] = (short)pb[e];
+      }
+      rb[c] = vb;
+      if (sum_b) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) csum[e] += __uint_as_float(((uint32_t)(uint16_t)vb[e]) << 16);
+      }
+    }
+  };
+  auto lstore = [&]() {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) *(s16x8*)(smem + (arow + 16 * c) * TN_LD + acol * 2) = ra[c];
+#pragma unroll
+    for (int c = 0; c < 7; ++c) {
+      const int r = brow + 10 * c;
+      if (bld && r < 64) *(s16x8*)(smem + A_BYTES + r * T192_LDB + bcol * 2) = rb[c];
+    }
+  };
+
+  f32x4 acc[4][6];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 6; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int i16 = lane & 15, fg = lane >> 4;
+  const int tra = (4 * fg + (i16 >> 2)) * TN_LD + 8 * (i16 & 3);
+  const int trb = (4 * fg + (i16 >> 2)) * T192_LDB + 8 * (i16 & 3);
+
+  gload(kt_begin);
+  lstore();
+  __syncthreads();
+  for (int kt = kt_begin; kt < kt_end; ++kt) {
+    if (kt + 1 < kt_end) gload(kt + 1);                      // global loads fly under the MFMAs of this tile
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 a[4], b[6];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const char* p = smem + ks * 32 * TN_LD + tra + (wr * 64 + i * 16) * 2;
+        s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)LDS_PTR(p));
+        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)LDS_PTR(p + 16 * TN_LD));
+        s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        a[i] = __builtin_bit_cast(bf16x8, v);
+      }
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        const char* p = smem + A_BYTES + ks * 32 * T192_LDB + trb + (wc * 96 + j * 16) * 2;
+        s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)LDS_PTR(p));
+        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)LDS_PTR(p + 16 * T192_LDB));
+        s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        b[j] = __builtin_bit_cast(bf16x8, v);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();                                         // everyone is done reading the single LDS buffer
+    if (kt + 1 < kt_end) lstore();
+    __syncthreads();
+  }
+
+  float* cs = (float*)smem;
+  if (sum_a) {          // 16 row-lanes hold partial sums of the same 8 columns of this block's A slice
+#pragma unroll
+    for (int e = 0; e < 8; ++e) cs[arow * 128 + acol + e] = csum[e];
+    __syncthreads();
+    if (tid < 128 && n1_0 + tid < N1) {
+      float t = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) t += cs[r * 128 + tid];
+      atomicAdd(&colsum[n1_0 + tid], t);
+    }
+    __syncthreads();
+  }
+  if (sum_b) {          // 10 row-lanes hold partial sums of the same 8 columns of B (the caller's A): first tile row only
+    if (bld) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) cs[brow * 192 + bcol + e] = csum[e];
+    }
+    __syncthreads();
+    if (tid < 192 && tid < N2) {
+      float t = 0.f;
+#pragma unroll
+      for (int r = 0; r < 10; ++r) t += cs[r * 192 + tid];
+      atomicAdd(&colsum[tid], t);
+    }
+    __syncthreads();
+  }
+  for (int h = 0; h < 2; ++h) {
+    __syncthreads();
+    if (wr == h) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 6; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) cs[(i * 16 + fg * 4 + r) * T192_CS + wc * 96 + j * 16 + i16] = acc[i][j][r];
+    }
+    __syncthreads();
+    for (int idx = tid; idx < 64 * 192; idx += 256) {
+      int rl, cl;
+      if (SWAP) { cl = idx >> 6; rl = idx & 63; }            // lanes run along n1 (contiguous in the caller's transposed C)
+      else { rl = idx / 192; cl = idx % 192; }
+      const int n1 = n1_0 + h * 64 + rl;
+      if (n1 < N1 && cl < N2) {
+        float* dst = SWAP ? &C[(size_t)cl * ldc + n1] : &C[(size_t)n1 * ldc + cl];
+        atomicAdd(dst, cs[rl * T192_CS + cl]);
+      }
+    }
+  }
+}
+
 }  // namespace
 
 // ---- optional launch probe (bench.py): HIP events around every NT-GEMM launch, on the stream it is launched on.
@@ -621,8 +790,26 @@ extern "C" int dkd_gemm_tn(const void* A, const void* B, float* C, int32_t M, in
   DKD_CHECK_ARG(M > 0 && N1 > 0 && N2 > 0, "gemm_tn: empty problem");
   DKD_CHECK_ARG(lda % 8 == 0 && ldb % 8 == 0, "gemm_tn: lda=%d / ldb=%d must be multiples of 8", lda, ldb);
   DKD_CHECK_ARG(((uintptr_t)A & 15) == 0 && ((uintptr_t)B & 15) == 0, "gemm_tn: A/B must be 16-byte aligned");
-  const int tiles = cdiv(N1, 128) * cdiv(N2, 128);
   const int KT = cdiv(M, 64);
+  const bool wide_b = N2 > 128 && N2 <= 192;                       // B is the 192-wide operand
+  const bool wide_a = !wide_b && N1 > 128 && N1 <= 192 && N2 > 192; // A is: swap roles, write transposed
+  if (wide_b || wide_a) {
+    const int t1 = cdiv(wide_b ? N1 : N2, 128);
+    int sp = cdiv(512, t1);
+    if (sp > cdiv(KT, 4)) sp = cdiv(KT, 4);
+    if (sp < 1) sp = 1;
+    const int per1 = cdiv(KT, sp);
+    sp = cdiv(KT, per1);
+    if (wide_b)
+      hipLaunchKernelGGL(gemm_tn192_kernel<false>, dim3(t1, sp), dim3(256), 0, as_stream(stream), (const bf16_t*)A, (const bf16_t*)B, C, M, N1,
+                         N2, lda, ldb, ldc, amap, bmap, per1, a_colsum);
+    else
+      hipLaunchKernelGGL(gemm_tn192_kernel<true>, dim3(t1, sp), dim3(256), 0, as_stream(stream), (const bf16_t*)B, (const bf16_t*)A, C, M, N2,
+                         N1, ldb, lda, ldc, bmap, amap, per1, a_colsum);
+    DKD_CHECK_LAUNCH("gemm_tn192");
+    return DKD_OK;
+  }
+  const int tiles = cdiv(N1, 128) * cdiv(N2, 128);
   // enough M-splits to fill 256 CUs x 2 blocks, but at least 4 k-tiles per block
   int splits = cdiv(512, tiles);
   if (splits > cdiv(KT, 4)) splits = cdiv(KT, 4);

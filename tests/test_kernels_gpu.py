@@ -113,6 +113,22 @@ def test_gemm_tn(ops, M, N1, N2):
     close(cs, 0.25 + a[:, :N1].float().sum(0), 1e-5 * math.sqrt(M), "tn fused column sums (bias gradient)")
 
 
+@pytest.mark.parametrize("N1,N2", [(64, 192), (192, 768), (576, 192), (192, 192), (100, 160)])
+def test_gemm_tn_wide_operand_paths(ops, N1, N2):
+    """128 x 192 wgrad tiles (the 192-wide operand as B, or as A with swapped roles + transposed store), row maps, bias sums."""
+    from deltakd_amd.ffi import strip_map
+    B, Nt = 7, 19
+    P = Nt - 1
+    a = rnd(B * P, (N1 + 7) // 8 * 8, seed=140).to(BF16)
+    b = rnd(B * Nt, (N2 + 7) // 8 * 8, seed=141).to(BF16)
+    out = torch.full((N1, N2), -0.5, device=dev())
+    cs = torch.zeros(N1, device=dev())
+    ops.gemm_tn(a, b, out, M=B * P, N1=N1, N2=N2, bmap=strip_map(Nt, 1), colsum=cs)
+    bs = b.view(B, Nt, -1)[:, 1:].reshape(B * P, -1)
+    close(out, -0.5 + a[:, :N1].float().t() @ bs[:, :N2].float(), 1e-4, "tn wide")
+    close(cs, a[:, :N1].float().sum(0), 1e-4, "tn wide bias sums")
+
+
 def test_gemm_tn_rowmaps(ops):
     from deltakd_amd.ffi import strip_map
     B, Nt, D1, D2 = 5, 18, 64, 128

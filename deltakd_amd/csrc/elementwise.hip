@@ -128,6 +128,56 @@ __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
   }
 }
 
+// Mixup / CutMix on a batch resident in HBM (timm Mixup mode='batch' [3P], reached from tools/engine.py:16-18): sample b is
+// mixed with sample B-1-b.  The pair is processed by ONE thread per element so the update is in place and race-free.
+//   mixup : x_b <- lam x_b + (1-lam) x_{B-1-b}        cutmix: the box [yl,yh) x [xl,xh) of x_b <- that of x_{B-1-b}
+__global__ void mixup_kernel(float* __restrict__ x, int B, int C, int H, int W, float lam, int cutmix, int yl, int yh, int xl, int xh) {
+  const long per = (long)C * H * W;
+  const long total4 = (long)(B / 2) * per / 4;
+  for (long t = blockIdx.x * (long)blockDim.x + threadIdx.x; t < total4; t += (long)gridDim.x * blockDim.x) {
+    const long e = t * 4;
+    const int b = (int)(e / per);
+    const long off = e % per;
+    float* pa = x + (long)b * per + off;
+    float* pb = x + (long)(B - 1 - b) * per + off;
+    const f32x4 a = *(const f32x4*)pa, c = *(const f32x4*)pb;
+    f32x4 na, nc;
+    if (!cutmix) {
+      na = a * lam + c * (1.f - lam);
+      nc = c * lam + a * (1.f - lam);
+    } else {
+      const int px = (int)(off % W), py = (int)((off / W) % H);
+      na = a;
+      nc = c;
+      if (py >= yl && py < yh) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (px + k >= xl && px + k < xh) {
+            na[k] = c[k];
+            nc[k] = a[k];
+          }
+      }
+    }
+    *(f32x4*)pa = na;
+    *(f32x4*)pb = nc;
+  }
+}
+
+// soft targets of timm's mixup_target: lam * smooth_onehot(y_b) + (1-lam) * smooth_onehot(y_{B-1-b})
+__global__ void mixup_target_kernel(const int64_t* __restrict__ y, float* __restrict__ out, int B, int C, float lam, float on, float off) {
+  const long total = (long)B * C;
+  for (long t = blockIdx.x * (long)blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+    const int b = (int)(t / C), c = (int)(t % C);
+    const float v1 = (int)y[b] == c ? on : off, v2 = (int)y[B - 1 - b] == c ? on : off;
+    out[t] = v1 * lam + v2 * (1.f - lam);
+  }
+}
+
+// EMA of the flat parameter buffer (timm ModelEma [3P], tools/engine.py:68-69): ema <- d ema + (1-d) p
+__global__ void ema_kernel(float* __restrict__ ema, const float* __restrict__ p, long n, float d) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) ema[i] = d * ema[i] + (1.f - d) * p[i];
+}
+
 inline int grid_for(long work, int block = 256, int cap = 4096) {
   long g = (work + block - 1) / block;
   return (int)(g < 1 ? 1 : (g > cap ? cap : g));
@@ -212,5 +262,30 @@ extern "C" int dkd_adamw_step(float* p, const float* g, float* m, float* v, void
   hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n, 256, 8192)), dim3(256), 0, as_stream(stream), p, g, m, v, (bf16_t*)p_bf16, (long)n, lr, beta1,
                      beta2, eps, weight_decay, bc1, bc2s, grad_scale);
   DKD_CHECK_LAUNCH("adamw");
+  return DKD_OK;
+}
+
+extern "C" int dkd_mixup(float* x, int32_t B, int32_t C, int32_t H, int32_t W, float lam, int32_t cutmix, int32_t yl, int32_t yh, int32_t xl,
+                         int32_t xh, void* stream) {
+  DKD_CHECK_ARG(x && B > 0 && B % 2 == 0, "mixup: batch size should be even (B=%d)", B);
+  DKD_CHECK_ARG(W % 4 == 0, "mixup: W=%d must be a multiple of 4", W);
+  hipLaunchKernelGGL(mixup_kernel, dim3(grid_for((long)(B / 2) * C * H * W / 4)), dim3(256), 0, as_stream(stream), x, B, C, H, W, lam, cutmix, yl,
+                     yh, xl, xh);
+  DKD_CHECK_LAUNCH("mixup");
+  return DKD_OK;
+}
+
+extern "C" int dkd_mixup_targets(const int64_t* labels, float* out, int32_t B, int32_t C, float lam, float smoothing, void* stream) {
+  DKD_CHECK_ARG(labels && out && B > 0 && C > 0, "mixup_targets: bad arguments");
+  const float off = smoothing / C, on = 1.f - smoothing + off;
+  hipLaunchKernelGGL(mixup_target_kernel, dim3(grid_for((long)B * C)), dim3(256), 0, as_stream(stream), labels, out, B, C, lam, on, off);
+  DKD_CHECK_LAUNCH("mixup_targets");
+  return DKD_OK;
+}
+
+extern "C" int dkd_ema_update(float* ema, const float* p, int64_t n, float decay, void* stream) {
+  DKD_CHECK_ARG(ema && p && n > 0, "ema_update: bad arguments");
+  hipLaunchKernelGGL(ema_kernel, dim3(grid_for(n, 256, 8192)), dim3(256), 0, as_stream(stream), ema, p, (long)n, decay);
+  DKD_CHECK_LAUNCH("ema_update");
   return DKD_OK;
 }

@@ -83,6 +83,10 @@ _SIGS = {
     "dkd_colsum": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, RowMap, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "dkd_add_rows": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, RowMap, C.c_int32, C.c_int32, C.c_int32,
                                C.c_void_p]),
+    "dkd_mixup": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                            C.c_int32, C.c_void_p]),
+    "dkd_mixup_targets": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_void_p]),
+    "dkd_ema_update": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_void_p]),
     "dkd_logit_loss": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int32, C.c_void_p, C.c_void_p, C.c_float,
                                  C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "dkd_mse_loss": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, RowMap, C.c_void_p, C.c_float,

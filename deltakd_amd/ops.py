@@ -315,3 +315,24 @@ def probe_end():
     fl, ms, n = (C.c_double * 3)(), (C.c_double * 3)(), (C.c_int32 * 3)()
     check(lib().dkd_probe_end(fl, ms, n), "probe_end")
     return {PROBE_SYMBOLS[i]: (fl[i], ms[i], n[i]) for i in range(3) if n[i]}
+
+
+def mixup_(x, lam, box=None):
+    """In-place Mixup (box=None) or CutMix (box=(yl, yh, xl, xh)) of a device batch f32 [B, C, H, W] with its flip."""
+    assert x.dtype == F32 and x.is_contiguous() and x.dim() == 4
+    B, Cc, H, W = x.shape
+    yl, yh, xl, xh = box if box is not None else (0, 0, 0, 0)
+    check(lib().dkd_mixup(ptr(x), B, Cc, H, W, lam, int(box is not None), int(yl), int(yh), int(xl), int(xh), stream()), "mixup")
+    return x
+
+
+def mixup_targets(labels, num_classes, lam, smoothing):
+    assert labels.dtype == torch.int64 and labels.is_contiguous()
+    out = torch.empty(labels.shape[0], num_classes, device=labels.device, dtype=F32)
+    check(lib().dkd_mixup_targets(ptr(labels), ptr(out), labels.shape[0], num_classes, lam, smoothing, stream()), "mixup_targets")
+    return out
+
+
+def ema_update(ema, p, decay):
+    assert ema.dtype == F32 and p.dtype == F32 and ema.numel() == p.numel()
+    check(lib().dkd_ema_update(ptr(ema), ptr(p), ema.numel(), decay, stream()), "ema_update")

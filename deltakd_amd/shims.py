@@ -79,18 +79,71 @@ class Mixup:
     def __call__(self, x, target):
         assert len(x) % 2 == 0, "Batch size should be even when using this"
         lam, use_cutmix = self._params_per_batch()
-        if lam != 1.:
-            if use_cutmix:
-                H, W = x.shape[-2:]
-                ratio = np.sqrt(1 - lam)
-                ch, cw = int(H * ratio), int(W * ratio)
-                cy, cx = np.random.randint(0, H), np.random.randint(0, W)
-                yl, yh = np.clip(cy - ch // 2, 0, H), np.clip(cy + ch // 2, 0, H)
-                xl, xh = np.clip(cx - cw // 2, 0, W), np.clip(cx + cw // 2, 0, W)
-                if self.correct_lam:
-                    lam = 1. - (yh - yl) * (xh - xl) / float(H * W)
+        box = None
+        if lam != 1. and use_cutmix:
+            H, W = x.shape[-2:]
+            ratio = np.sqrt(1 - lam)
+            ch, cw = int(H * ratio), int(W * ratio)
+            cy, cx = np.random.randint(0, H), np.random.randint(0, W)
+            yl, yh = np.clip(cy - ch // 2, 0, H), np.clip(cy + ch // 2, 0, H)
+            xl, xh = np.clip(cx - cw // 2, 0, W), np.clip(cx + cw // 2, 0, W)
+            box = (int(yl), int(yh), int(xl), int(xh))
+            if self.correct_lam:
+                lam = 1. - (yh - yl) * (xh - xl) / float(H * W)
+        if x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and x.shape[-1] % 4 == 0:
+            # batch already resident in HBM: one fused in-place kernel + one soft-target kernel; the
+            # lambda / box draws stay on the host's numpy RNG exactly as in timm
+            from . import ops
+            if lam != 1.:
+                ops.mixup_(x, float(lam), box)
+            tgt = target.to(device=x.device, dtype=torch.int64).contiguous()
+            return x, ops.mixup_targets(tgt, self.num_classes, float(lam), self.label_smoothing)
+        if lam != 1.:                       # host tensors (the reference mixes before the H2D copy): plain torch
+            if box is not None:
+                yl, yh, xl, xh = box
                 x[:, :, yl:yh, xl:xh] = x.flip(0)[:, :, yl:yh, xl:xh]
             else:
                 x_flipped = x.flip(0).mul_(1. - lam)
                 x.mul_(lam).add_(x_flipped)
         return x, mixup_target(target, self.num_classes, lam, self.label_smoothing)
+
+
+class ModelEma:
+    """timm.utils.ModelEma's contract (``ModelEma(model, decay)``, ``.update(model)``, ``.ema`` holding the averaged weights) on flat
+    storage: when the student's parameters live in FusedAdamW's flat buffers the whole update is one kernel per buffer."""
+
+    def __init__(self, model, decay=0.9999, device=None, resume="", optimizer=None):
+        import copy
+        inner = model.module if hasattr(model, "module") else model
+        self.decay = decay
+        self.ema = copy.deepcopy(inner).eval()
+        for p in self.ema.parameters():
+            p.requires_grad_(False)
+        self._flat = None
+        flats = getattr(optimizer, "_flat", None)
+        if flats:
+            # mirror the optimizer's flat layout so that update() is a single launch per weight-decay group
+            self._flat = []
+            where = optimizer._where
+            own = dict(inner.named_parameters())
+            ema_named = dict(self.ema.named_parameters())
+            for f in flats:
+                self._flat.append(None if f is None else (f["p"], f["p"].clone()))
+            for name, p in own.items():
+                w = where.get(id(p))
+                if w is not None and name in ema_named:
+                    i, s, e = w
+                    ema_named[name].data = self._flat[i][1][s:s + p.numel()].view(p.shape)
+
+    @torch.no_grad()
+    def update(self, model):
+        if self._flat is not None:
+            from . import ops
+            for pair in self._flat:
+                if pair is not None:
+                    ops.ema_update(pair[1], pair[0], self.decay)
+            return
+        inner = model.module if hasattr(model, "module") else model
+        for (k, ev), (_, mv) in zip(self.ema.state_dict().items(), inner.state_dict().items()):
+            if ev.dtype.is_floating_point:
+                ev.mul_(self.decay).add_(mv.detach(), alpha=1. - self.decay)

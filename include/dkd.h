@@ -115,6 +115,15 @@ int dkd_colsum(const void* x, int32_t x_is_f32, int32_t ldx, DkdRowMap xmap, flo
 int dkd_add_rows(const void* x, int32_t x_is_f32, int32_t ldx, float* y, int32_t ldy, DkdRowMap ymap, int32_t M, int32_t D,
                  int32_t accumulate, void* stream);
 
+/* Mixup / CutMix on a device-resident batch (timm Mixup mode='batch' [3P], tools/engine.py:16-18):
+ * in place, sample b with sample B-1-b.  cutmix = 0: x_b <- lam x_b + (1-lam) x_{B-1-b}; cutmix = 1: box [yl,yh) x [xl,xh) swapped in. */
+int dkd_mixup(float* x, int32_t B, int32_t C, int32_t H, int32_t W, float lam, int32_t cutmix, int32_t yl, int32_t yh, int32_t xl,
+              int32_t xh, void* stream);
+/* out f32 [B, C] = lam * smooth_onehot(labels[b]) + (1-lam) * smooth_onehot(labels[B-1-b])   (timm mixup_target). */
+int dkd_mixup_targets(const int64_t* labels, float* out, int32_t B, int32_t C, float lam, float smoothing, void* stream);
+/* ema <- decay * ema + (1 - decay) * p over a flat parameter buffer (timm ModelEma [3P], tools/engine.py:68-69). */
+int dkd_ema_update(float* ema, const float* p, int64_t n, float decay, void* stream);
+
 /* ---------------------------------------------------------------- losses (fused value + gradient) */
 /* Base criterion + optional logit distillation in one pass (model/loss.py:35,57-67,241; timm SoftTargetCrossEntropy /
  * LabelSmoothingCrossEntropy [3P]).  z f32 [B, C] student logits; exactly one of soft_target f32 [B, C] / labels i64 [B].

@@ -451,3 +451,38 @@ def test_gemm_nt_wide_tile_kernel(ops):
     x = pre.float().requires_grad_(True)
     torch.nn.functional.gelu(x).backward(a.float() @ b.float().t())
     close(dh, x.grad, 1e-2, "wide dgelu")
+
+
+def test_mixup_kernels_match_the_host_path():
+    """Device Mixup / CutMix (fused kernels) == the torch host path of the shim, for the same numpy draws."""
+    import numpy as np
+    from deltakd_amd.shims import Mixup
+    for cutmix_alpha, mixup_alpha in ((0.0, 0.8), (1.0, 0.0), (1.0, 0.8)):
+        for seed in (0, 1, 2):
+            x = rnd(8, 3, 32, 32, seed=150 + seed)
+            y = torch.randint(0, 10, (8,), generator=torch.Generator().manual_seed(seed)).to(dev())
+            mix = Mixup(mixup_alpha=mixup_alpha, cutmix_alpha=cutmix_alpha, num_classes=10, label_smoothing=0.1)
+            np.random.seed(seed)
+            xd, yd = mix(x.clone(), y)
+            np.random.seed(seed)
+            xh, yh = mix(x.cpu().clone(), y.cpu())
+            close(xd.cpu(), xh, 1e-6, "mixed images")
+            close(yd.cpu(), yh, 1e-6, "soft targets")
+
+
+def test_ema_on_flat_storage():
+    from types import SimpleNamespace
+    from deltakd_amd import vit
+    from deltakd_amd.optim import create_optimizer
+    from deltakd_amd.shims import ModelEma
+    m = vit.VisionTransformer(64, 2, 1, 10, False, 0.0, img_size=32, patch_size=8, mlp_ratio=2.0).to(dev())
+    opt = create_optimizer(SimpleNamespace(opt="adamw", lr=1e-2, weight_decay=0.05, opt_eps=1e-8, opt_betas=None), m)
+    ema = ModelEma(m, decay=0.9, optimizer=opt)
+    before = {k: v.clone() for k, v in m.state_dict().items()}
+    for p in m.parameters():
+        p.grad.normal_()
+    opt.step()
+    ema.update(m)
+    for k, v in ema.ema.state_dict().items():
+        want = 0.9 * before[k] + 0.1 * m.state_dict()[k]
+        close(v, want, 1e-6, k)

@@ -1,4 +1,5 @@
-"""MGD, WassKD-L1 and DiffKD terms on libdkd.so (model/loss.py:229-236 + :422-452, :177-227, :105-155 of the reference).
+"""MGD, WassKD-L1, DiffKD, ViTKD and CurKD terms on libdkd.so (model/loss.py:229-236 + :422-452, :177-227, :105-155, :251-311,
+:362-420 of the reference).
 
 Each term is one autograd node whose forward runs the fused value+gradient kernels and whose backward is GEMMs only.
 Random draws (masking noise, diffusion step, gaussian noise, dropout keep mask) come from torch's device generator unless
@@ -20,15 +21,15 @@ class _MgdFn(torch.autograd.Function):
     """align -> where(mask, mask_token, .) -> Conv3x3 -> ReLU -> Conv3x3 -> masked MSE vs the teacher's last tap."""
 
     @staticmethod
-    def forward(ctx, tap, sm, t_tap, mask, scale, npre_s, npre_t):
+    def forward(ctx, tap, sm, align, t_tap, mask, scale, npre_s, npre_t):
         B, N, Ds = tap.shape
         P = N - npre_s
         hw = int(P ** 0.5)
-        M, Dt = B * P, sm.align.out_features
+        M, Dt = B * P, align.out_features
         sh = sm._shadow
         tap2 = tap.reshape(B * N, Ds)
         c1, c2 = sm.generation[0], sm.generation[2]
-        s = ops.gemm_nt(tap2, sh.get(sm.align.weight), M=M, amap=strip_map(N, npre_s), bias=sm.align.bias)
+        s = ops.gemm_nt(tap2, sh.get(align.weight), M=M, amap=strip_map(N, npre_s), bias=align.bias)
         xt = ops.mask_select(s, sm.mask_token.detach().reshape(-1).contiguous(), mask)
         cols1 = ops.im2col3x3(xt, B, hw)
         y1 = ops.gemm_nt(cols1, sh.get(c1.weight, conv3x3=True), bias=c1.bias, relu=True)
@@ -37,12 +38,12 @@ class _MgdFn(torch.autograd.Function):
         loss = torch.zeros(1, device=tap.device, dtype=F32)
         Nt = t_tap.shape[1]
         dy2 = ops.mse_loss(y2, t_tap.reshape(B * Nt, Dt), loss, scale / (M * Dt), M=M, tmap=strip_map(Nt, npre_t), mask=mask)
-        ctx.sm, ctx.saved, ctx.dims = sm, (tap2, cols1, y1, cols2, dy2, mask), (B, N, Ds, npre_s, hw, M, Dt)
+        ctx.sm, ctx.align, ctx.saved, ctx.dims = sm, align, (tap2, cols1, y1, cols2, dy2, mask), (B, N, Ds, npre_s, hw, M, Dt)
         return loss[0]
 
     @staticmethod
     def backward(ctx, g):
-        sm = ctx.sm
+        sm, align = ctx.sm, ctx.align
         sh = sm._shadow
         tap2, cols1, y1, cols2, dy2, mask = ctx.saved
         B, N, Ds, npre, hw, M, Dt = ctx.dims
@@ -63,11 +64,11 @@ class _MgdFn(torch.autograd.Function):
         dxt = ops.col2im3x3(dcols, B, hw)
         ds = ops.mask_select_bwd(dxt, mask, ensure_grad(sm.mask_token).view(-1))
         smap = strip_map(N, npre)
-        ops.gemm_tn(ds, tap2, ensure_grad(sm.align.weight), M=M, bmap=smap, colsum=ensure_grad(sm.align.bias))
+        ops.gemm_tn(ds, tap2, ensure_grad(align.weight), M=M, bmap=smap, colsum=ensure_grad(align.bias))
         dtap = torch.zeros(B * N, Ds, device=ds.device, dtype=BF16)
-        ops.gemm_nt(ds, sh.get(sm.align.weight, transposed=True), out=dtap, cmap=smap)
+        ops.gemm_nt(ds, sh.get(align.weight, transposed=True), out=dtap, cmap=smap)
         ctx.saved = None
-        return dtap.view(B, N, Ds), None, None, None, None, None, None
+        return dtap.view(B, N, Ds), None, None, None, None, None, None, None
 
 
 def mgd_loss(student_model, student_features, teacher_features, args, *, npre_s=1, npre_t=2, noise=None):
@@ -78,7 +79,8 @@ def mgd_loss(student_model, student_features, teacher_features, args, *, npre_s=
     if noise is None:
         noise = torch.rand(B, P, device=tap.device)
     mask, _, _, _ = masking_indices(noise, args.mgd_mask_ratio)
-    return _MgdFn.apply(tap, student_model, teacher_features[-1], mask.reshape(-1).contiguous(), float(args.mgd_alpha), npre_s, npre_t)
+    return _MgdFn.apply(tap, student_model, student_model.align, teacher_features[-1], mask.reshape(-1).contiguous(),
+                        float(args.mgd_alpha), npre_s, npre_t)
 
 
 # ----------------------------------------------------------------------------------------------- WassKD (L1)
@@ -175,4 +177,54 @@ def diffkd_loss(student_model, student_features, teacher_features, alpha, npre_s
             return ops.normalize_mse(s, t_hat, loss, scale / (M * Dt), w_scalar=w_mean, ld_grad=Kp)
         term_match = _AlignTermFn.apply(sel_s[i], sm.align[i], sm._shadow, npre_s, cb)
         total = term_dn + term_match if total is None else total + term_dn + term_match
+    return total
+
+
+# ----------------------------------------------------------------------------------------------- ViTKD / CurKD
+def _sum_mse_term(tap, align, shadow, t_tap, scale_per_batch, npre_s, npre_t):
+    """scale * sum((align(tap[:, npre:]) - t[:, npre_t:])^2) / B   (nn.MSELoss(reduction='sum') / B of the reference)."""
+    from .losses import align_mse_term
+    B, N, _ = tap.shape
+    P = N - npre_s
+    Nt, Dt = t_tap.shape[1], t_tap.shape[2]
+    # align_mse_term computes scale * mean over B*P*Dt elements: sum / B = mean * P * Dt
+    return align_mse_term(tap, align, shadow, t_tap.reshape(B * Nt, Dt), strip_map(Nt, npre_t), scale_per_batch * P * Dt, npre_s)
+
+
+def _masked_generation_term(student_model, align, tap, t_tap, ratio, scale_per_batch, npre_s, npre_t, noise):
+    B, N, _ = tap.shape
+    P = N - npre_s
+    if noise is None:
+        noise = torch.rand(B, P, device=tap.device)
+    mask, _, _, _ = masking_indices(noise, ratio)
+    Dt = t_tap.shape[2]
+    return _MgdFn.apply(tap, student_model, align, t_tap, mask.reshape(-1).contiguous(), scale_per_batch * P * Dt, npre_s, npre_t)
+
+
+def vitkd_loss(student_model, student_features, teacher_features, alpha_vitkd=0.00003, beta_vitkd=0.000003, lambda_vitkd=0.5, *,
+               npre_s=1, npre_t=2, noise=None):
+    """model/loss.py:251-311: sum-reduced mimicking of blocks 0, 1 through ``align2`` + masked generation on the last block."""
+    sm = student_model
+    total = None
+    for i in range(2):
+        term = _sum_mse_term(student_features[i], sm.align2[i], sm._shadow, teacher_features[i], alpha_vitkd, npre_s, npre_t)
+        total = term if total is None else total + term
+    return total + _masked_generation_term(sm, sm.align, student_features[-1], teacher_features[-1], lambda_vitkd,
+                                           beta_vitkd / lambda_vitkd, npre_s, npre_t, noise)
+
+
+def curkd_loss(student_model, student_features, teacher_features, args, *, npre_s=1, npre_t=2, noise=None):
+    """model/loss.py:362-420: epoch curriculum -- blocks 0-2 (epoch < 100), blocks 3-6 (< 151), then masked generation on block 11."""
+    sm = student_model
+    epoch = args.current_epoch
+    if epoch < 100:
+        layers, mods, div = range(3), sm.curkd_align_early, 3.0
+    elif epoch < 151:
+        layers, mods, div = range(3, 7), sm.curkd_align_mid, 4.0
+    else:
+        return _masked_generation_term(sm, sm.curkd_align_last, student_features[11], teacher_features[11], 0.5, 5e-5, npre_s, npre_t, noise)
+    total = None
+    for j, i in enumerate(layers):
+        term = _sum_mse_term(student_features[i], mods[j], sm._shadow, teacher_features[i], 4e-5 / div, npre_s, npre_t)
+        total = term if total is None else total + term
     return total

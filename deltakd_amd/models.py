@@ -75,6 +75,17 @@ def attach_aux(student, teacher, distillation_type, args=None):
         student.generation = Generation(dt)
     elif kind == "wasskd":
         student.align_wasskd = nn.ModuleList([_linear_default(ds, dt) for _ in range(3)])
+    elif kind == "vitkd":                                   # model/models.py:76-88
+        student.align2 = nn.ModuleList([_linear_default(ds, dt) for _ in range(2)])
+        student.align = _linear_default(ds, dt)
+        student.mask_token = nn.Parameter(torch.zeros(1, 1, dt))
+        student.generation = Generation(dt)
+    elif kind == "curkd":                                   # model/models.py:153-167
+        student.curkd_align_early = nn.ModuleList([_linear_default(ds, dt) for _ in range(3)])
+        student.curkd_align_mid = nn.ModuleList([_linear_default(ds, dt) for _ in range(4)])
+        student.curkd_align_last = _linear_default(ds, dt)
+        student.mask_token = nn.Parameter(torch.zeros(1, 1, dt))
+        student.generation = Generation(dt)
     return student
 
 

@@ -107,6 +107,10 @@ def main():
         ("mgd", "mgd", "deit_toy_student", dict(mgd_alpha=7e-5, mgd_mask_ratio=0.5), (True,)),
         ("wasskd", "wasskd", "deit_toy_student", dict(wasskd_type="l1"), (True,)),
         ("diffkd", "diffkd", "deit_toy_student", dict(alpha=0.1), (False,)),
+        ("vitkd", "vitkd", "deit_toy_student", dict(), (True,)),
+        ("curkd_early", "curkd", "deit_toy_student", dict(current_epoch=0), (False,)),
+        ("curkd_mid", "curkd", "deit_toy_student", dict(current_epoch=120), (True,)),
+        ("curkd_late", "curkd", "deit_toy_student", dict(current_epoch=200), (True,)),
     ]
     teacher_saved = False
     for tag, kind, sname, extra, label_kinds in branches:
@@ -172,7 +176,7 @@ def main():
             torch.manual_seed(99)
             P = student.patch_embed.num_patches
             Dt = teacher.embed_dim
-            if kind == "mgd":
+            if kind in ("mgd", "vitkd") or (kind == "curkd" and args.current_epoch >= 151):
                 draws["noise"] = torch.rand(B, P)
                 draws_np["draw.noise"] = draws["noise"].numpy()
             if kind == "diffkd":

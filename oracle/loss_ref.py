@@ -91,6 +91,17 @@ def attach_aux_ref(student, teacher, kind, lrkd_rank=64):
         student.generation = gen()
     elif kind == "wasskd":
         student.align_wasskd = nn.ModuleList([nn.Linear(ds, dt) for _ in range(3)])
+    elif kind == "vitkd":                                   # model/models.py:76-88
+        student.align2 = nn.ModuleList([nn.Linear(ds, dt) for _ in range(2)])
+        student.align = nn.Linear(ds, dt)
+        student.mask_token = nn.Parameter(torch.zeros(1, 1, dt))
+        student.generation = gen()
+    elif kind == "curkd":                                   # model/models.py:153-167
+        student.curkd_align_early = nn.ModuleList([nn.Linear(ds, dt) for _ in range(3)])
+        student.curkd_align_mid = nn.ModuleList([nn.Linear(ds, dt) for _ in range(4)])
+        student.curkd_align_last = nn.Linear(ds, dt)
+        student.mask_token = nn.Parameter(torch.zeros(1, 1, dt))
+        student.generation = gen()
     elif kind in ("soft", "hard"):
         if hasattr(student, "set_distilled_training"):
             student.set_distilled_training(True)
@@ -180,6 +191,41 @@ def diffkd_ref(student, s_feats, t_feats, pre_s, pre_t, t, noises, drops):
     return feat / 3 * 5e-5
 
 
+def _masked_generation_ref(student, x, t, ratio, noise):
+    """gather-keep -> cat(mask_token) -> restore -> Conv3x3-ReLU-Conv3x3; returns (generated tokens, mask [B, N, 1])."""
+    B, N, D = x.shape
+    keep, mask, ids_restore, _ = random_masking_ref(x, ratio, noise)
+    x_ = torch.cat([keep, student.mask_token.repeat(B, N - keep.shape[1], 1)], 1)
+    x = torch.gather(x_, 1, ids_restore.unsqueeze(-1).repeat(1, 1, D))
+    hw = int(N ** 0.5)
+    x = student.generation(x.reshape(B, hw, hw, D).permute(0, 3, 1, 2)).flatten(2).transpose(1, 2)
+    return x, mask.unsqueeze(-1)
+
+
+def vitkd_ref(student, s_feats, t_feats, pre_s, pre_t, noise, alpha_vitkd=0.00003, beta_vitkd=0.000003, lambda_vitkd=0.5):
+    """model/loss.py:251-311: sum-reduced mimicking on blocks 0,1 + masked generation on the last block."""
+    B = s_feats[0].shape[0]
+    lr = 0.0
+    for i in range(2):
+        lr = lr + ((student.align2[i](s_feats[i][:, pre_s:]) - t_feats[i][:, pre_t:]) ** 2).sum()
+    x, m = _masked_generation_ref(student, student.align(s_feats[-1][:, pre_s:]), None, lambda_vitkd, noise)
+    gen = ((x * m - t_feats[-1][:, pre_t:] * m) ** 2).sum()
+    return lr / B * alpha_vitkd + gen / B * beta_vitkd / lambda_vitkd
+
+
+def curkd_ref(student, s_feats, t_feats, pre_s, pre_t, epoch, noise):
+    """model/loss.py:362-420: epoch curriculum (early blocks 0-2, mid blocks 3-6, late masked generation on block 11)."""
+    B = s_feats[0].shape[0]
+    if epoch < 100:
+        tot = sum(((student.curkd_align_early[i](s_feats[i][:, pre_s:]) - t_feats[i][:, pre_t:]) ** 2).sum() for i in range(3))
+        return tot / 3.0 / B * 4e-5
+    if epoch < 151:
+        tot = sum(((student.curkd_align_mid[i - 3](s_feats[i][:, pre_s:]) - t_feats[i][:, pre_t:]) ** 2).sum() for i in range(3, 7))
+        return tot / 4.0 / B * 4e-5
+    x, m = _masked_generation_ref(student, student.curkd_align_last(s_feats[11][:, pre_s:]), None, 0.5, noise)
+    return ((x * m - t_feats[11][:, pre_t:] * m) ** 2).sum() / B * 5e-5
+
+
 class DistillationLossRef(nn.Module):
     """Same constructor/call contract as model/loss.py:19-29, plus ``draws``.
 
@@ -225,6 +271,10 @@ class DistillationLossRef(nn.Module):
             if args.wasskd_type != "l1":
                 raise NotImplementedError("sinkhorn: geomloss oracle unavailable (parity unpinned)")
             return base + 5.0 * wasskd_l1_ref(student_model, student_features, tf, ps, pt)
+        elif kind == "vitkd":
+            return base + vitkd_ref(student_model, student_features, tf, ps, pt, draws["noise"])
+        elif kind == "curkd":
+            return base + curkd_ref(student_model, student_features, tf, ps, pt, args.current_epoch, draws.get("noise"))
         elif kind == "mgd":
             return base + mgd_ref(student_model, student_features, tf, ps, pt, args.mgd_mask_ratio,
                                   args.mgd_alpha, draws["noise"])

@@ -13,7 +13,8 @@ from oracle import loss_ref, vit_ref
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 TOY = dict(img_size=32, patch_size=8, mlp_ratio=2.0)
 CASES = ["none_hardlabel", "none_softlabel", "soft_softlabel", "hard_hardlabel", "lrkd_hardlabel", "lrkd_softlabel",
-         "mgd_softlabel", "wasskd_softlabel", "diffkd_hardlabel"]
+         "mgd_softlabel", "wasskd_softlabel", "diffkd_hardlabel", "vitkd_softlabel", "curkd_early_hardlabel", "curkd_mid_softlabel",
+         "curkd_late_softlabel"]
 
 
 def build(fx, tsd):
@@ -37,7 +38,7 @@ def test_oracle_reproduces_reference(name):
     target = torch.from_numpy(fx["soft_targets"] if int(fx["use_soft_label"]) else fx["labels"])
     student.set_droppath_keep([torch.from_numpy(k.astype(np.float32)) for k in fx["keep"]])
     draws = {}
-    if kind == "mgd":
+    if "draw.noise" in fx:
         draws["noise"] = torch.from_numpy(fx["draw.noise"])
     if kind == "diffkd":
         draws = {"t": torch.from_numpy(fx["draw.t"]), "noise": [torch.from_numpy(fx[f"draw.noise{i}"]) for i in range(3)],

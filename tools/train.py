@@ -6,7 +6,7 @@ Orchestration only (out of scope as an acceleration tar
 deltakd_amd: HIP models, fused losses, FusedAdamW, RCCL data parallel.  Datasets: torchvision is absent on the MI355X
 boxes and nothing can be downloaded, so ``--data-path`` is only used when torchvision is importable; otherwise (or with
 ``--synthetic-batches N``) batches are synthetic tensors of the dataset's shape and class count, generated on the device.
-Not carried over: wandb, thop FLOP counting, checkpoint save/resume/finetune, EMA (all I/O or disabled by default).
+Not carried over: wandb, thop FLOP counting, checkpoint save/resume/finetune (I/O, out of scope).
 """
 import argparse
 import os
@@ -23,7 +23,7 @@ from deltakd_amd.engine import train_one_epoch, validate  # noqa: E402
 from deltakd_amd.losses import DistillationLoss, call_base_loss  # noqa: E402
 from deltakd_amd.models import DATASET_NUM_CLASSES, load_teacher_student_model  # noqa: E402
 from deltakd_amd.optim import create_optimizer, create_scheduler  # noqa: E402
-from deltakd_amd.shims import Mixup, NativeScaler  # noqa: E402
+from deltakd_amd.shims import Mixup, ModelEma, NativeScaler  # noqa: E402
 from tools.utils import seed_everything, setup_device, setup_distributed  # noqa: E402
 
 DISTILL_TYPES = ['none', 'soft', 'hard', 'vitkd', 'aaakd', 'vitkd_w_logit', 'aaakd_w_logit', 'lrkd', 'diffkd', 'saliency_mgd', 'curkd',
@@ -107,9 +107,10 @@ def main(argv=None):
     criterion = DistillationLoss(call_base_loss(args), teacher, args.distillation_type, args.alpha, args.tau,
                                  teacher_stream=torch.cuda.Stream() if device.type == "cuda" else None)
     model = DataParallel(student, optimizer) if args.distributed else student
+    model_ema = ModelEma(student, decay=args.ema_decay, optimizer=optimizer) if args.ema_decay else None
     for epoch in range(args.epochs):
         tm = train_one_epoch(student_model=model, teacher_model=teacher, train_loader=train_loader, criterion=criterion,
-                             optimizer=optimizer, loss_scaler=loss_scaler, clip_grad=args.clip_grad, mixup_fn=mixup_fn, model_ema=None,
+                             optimizer=optimizer, loss_scaler=loss_scaler, clip_grad=args.clip_grad, mixup_fn=mixup_fn, model_ema=model_ema,
                              device=device, epoch=epoch, args=args)
         scheduler.step(epoch)
         vm = validate(model, val_loader, device, args)

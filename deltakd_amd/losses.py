@@ -297,7 +297,7 @@ class DistillationLoss(nn.Module):
         if outputs_kd is None and kind in ("soft", "hard"):
             raise ValueError("When knowledge distillation is enabled, the model is expected to return a Tuple[Tensor, Tensor] "
                              "with the output of the class_token and the dist_token")
-        if kind not in ("soft", "hard", "lrkd", "mgd", "wasskd", "diffkd", "vitkd", "curkd"):
+        if kind not in ("soft", "hard", "lrkd", "mgd", "wasskd", "diffkd", "vitkd", "curkd", "saliency_mgd"):
             raise ValueError(f"Invalid distillation type: {self.distillation_type}")
 
         self._lrkd_rank = getattr(args, "lrkd_rank", 0)
@@ -329,6 +329,9 @@ class DistillationLoss(nn.Module):
         if kind == "mgd":
             return self._base(outputs, labels, 1.0) + losses_ext.mgd_loss(sm, student_features, t_taps, args, npre_s=ps, npre_t=pt,
                                                                            noise=self.injected.get("noise"))
+        if kind == "saliency_mgd":
+            return self._base(outputs, labels, 1.0) + losses_ext.saliency_mgd_loss(sm, student_features, t_taps, args, npre_s=ps, npre_t=pt,
+                                                                                    scores=self.injected.get("scores"))
         if kind == "vitkd":
             return self._base(outputs, labels, 1.0) + losses_ext.vitkd_loss(sm, student_features, t_taps, 0.00003, 0.000003, 0.5, npre_s=ps,
                                                                              npre_t=pt, noise=self.injected.get("noise"))

@@ -12,7 +12,7 @@ import torch
 from . import ops
 from .ffi import IDENT, RowMap, strip_map
 from .losses import _AlignTermFn, _grad_buffer, _pad64
-from .misc import masking_indices
+from .misc import masking_indices, saliency_scores
 from .vit import BF16, F32, ensure_grad
 
 
@@ -228,3 +228,13 @@ def curkd_loss(student_model, student_features, teacher_features, args, *, npre_
         term = _sum_mse_term(student_features[i], mods[j], sm._shadow, teacher_features[i], 4e-5 / div, npre_s, npre_t)
         total = term if total is None else total + term
     return total
+
+
+def saliency_mgd_loss(student_model, student_features, teacher_features, args, *, npre_s=1, npre_t=2, scores=None):
+    """model/loss.py:335-360: MGD whose mask keeps the lowest-saliency tokens (scores from ``student_model.saliency_attn`` applied to
+    the teacher's last tap); 4 * mean((G(x~) m - t m)^2)."""
+    t_tap = teacher_features[-1]
+    if scores is None:
+        scores = saliency_scores(student_model, t_tap, args.saliency_method, npre_t)
+    mask, _, _, _ = masking_indices(scores, args.saliency_mask_ratio)
+    return _MgdFn.apply(student_features[-1], student_model, student_model.align, t_tap, mask.reshape(-1).contiguous(), 4.0, npre_s, npre_t)

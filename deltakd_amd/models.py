@@ -48,6 +48,39 @@ class DenoisingNetwork(nn.Module):
                 m.bias.copy_(ref.bias)
 
 
+class SimpleAttention(nn.Module):
+    """model/models.py:38-56 (saliency scorer).  Only ever used to RANK tokens (argsort), so it carries no gradient; its small
+    [B*196, Dt] x [Dt, 2 Dt] projection and per-head softmax run as torch glue (rocBLAS), not as a libdkd kernel."""
+
+    def __init__(self, dim, num_heads=8):
+        super().__init__()
+        self.num_heads, self.scale = num_heads, (dim // num_heads) ** -0.5
+        self.qk = nn.Linear(dim, dim * 2, bias=True)
+
+    def forward(self, x):
+        B, N, C = x.shape
+        qk = self.qk(x).reshape(B, N, 2, self.num_heads, C // self.num_heads).permute(2, 0, 3, 1, 4)
+        attn = ((qk[0] @ qk[1].transpose(-2, -1)) * self.scale).softmax(dim=-1)
+        return attn.mean(dim=1).diagonal(dim1=-2, dim2=-1)
+
+
+class SimpleCrossAttention(nn.Module):
+    """model/models.py:14-35."""
+
+    def __init__(self, dim, num_heads=8):
+        super().__init__()
+        self.num_heads, self.scale = num_heads, (dim // num_heads) ** -0.5
+        self.q = nn.Linear(dim, dim, bias=True)
+        self.k = nn.Linear(dim, dim, bias=True)
+
+    def forward(self, x_query, x_key):
+        B, Nq, C = x_query.shape
+        Nk = x_key.shape[1]
+        q = self.q(x_query).reshape(B, Nq, self.num_heads, C // self.num_heads).permute(0, 2, 1, 3)
+        k = self.k(x_key).reshape(B, Nk, self.num_heads, C // self.num_heads).permute(0, 2, 1, 3)
+        return ((q @ k.transpose(-2, -1)) * self.scale).softmax(dim=-1).mean(dim=1)
+
+
 def _linear_default(i, o):
     """Linear holder with nn.Linear's default (kaiming-uniform) init, as the reference's aux nn.Linear layers get."""
     m, ref = Linear(i, o), nn.Linear(i, o)
@@ -75,6 +108,12 @@ def attach_aux(student, teacher, distillation_type, args=None):
         student.generation = Generation(dt)
     elif kind == "wasskd":
         student.align_wasskd = nn.ModuleList([_linear_default(ds, dt) for _ in range(3)])
+    elif kind == "saliency_mgd":                            # model/models.py:129-143
+        student.align = _linear_default(ds, dt)
+        student.mask_token = nn.Parameter(torch.zeros(1, 1, dt))
+        student.generation = Generation(dt)
+        method = getattr(args, "saliency_method", 1)
+        student.saliency_attn = SimpleCrossAttention(dt, num_heads=8) if method == 3 else SimpleAttention(dt, num_heads=8)
     elif kind == "vitkd":                                   # model/models.py:76-88
         student.align2 = nn.ModuleList([_linear_default(ds, dt) for _ in range(2)])
         student.align = _linear_default(ds, dt)

@@ -111,6 +111,9 @@ def main():
         ("curkd_early", "curkd", "deit_toy_student", dict(current_epoch=0), (False,)),
         ("curkd_mid", "curkd", "deit_toy_student", dict(current_epoch=120), (True,)),
         ("curkd_late", "curkd", "deit_toy_student", dict(current_epoch=200), (True,)),
+        ("saliency1", "saliency_mgd", "deit_toy_student", dict(saliency_method=1, saliency_mask_ratio=0.5), (True,)),
+        ("saliency2", "saliency_mgd", "deit_toy_student", dict(saliency_method=2, saliency_mask_ratio=0.5), (False,)),
+        ("saliency3", "saliency_mgd", "deit_toy_student", dict(saliency_method=3, saliency_mask_ratio=0.5), (True,)),
     ]
     teacher_saved = False
     for tag, kind, sname, extra, label_kinds in branches:
@@ -189,6 +192,10 @@ def main():
                 for i in range(3):
                     draws_np[f"draw.noise{i}"] = draws["noise"][i].numpy()
                     draws_np[f"draw.drop{i}"] = draws["drop"][i].numpy().astype(np.uint8)
+            if kind == "saliency_mgd":
+                with torch.no_grad():
+                    sc = loss_ref.saliency_scores_ref(student.saliency_attn, t_feats[-1], args.saliency_method)
+                draws_np["draw.scores"] = sc.numpy()
             if kind == "lrkd":
                 sel = [t_feats[0], t_feats[1], t_feats[11]]
                 draws["lrkd_targets"] = [loss_ref.lrkd_targets_ref(f[:, 2:], args.lrkd_rank) for f in sel]

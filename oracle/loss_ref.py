@@ -74,7 +74,67 @@ class DenoisingNetworkRef(nn.Module):
         return y * drop_keep / 0.9
 
 
-def attach_aux_ref(student, teacher, kind, lrkd_rank=64):
+class SimpleAttentionRef(nn.Module):
+    """model/models.py:38-56: per-head softmax(q k^T / sqrt(d)) averaged over heads; returns its diagonal [B, N]."""
+
+    def __init__(self, dim, num_heads=8):
+        super().__init__()
+        self.num_heads, self.scale = num_heads, (dim // num_heads) ** -0.5
+        self.qk = nn.Linear(dim, dim * 2, bias=True)
+
+    def forward(self, x):
+        B, N, C = x.shape
+        qk = self.qk(x).reshape(B, N, 2, self.num_heads, C // self.num_heads).permute(2, 0, 3, 1, 4)
+        attn = ((qk[0] @ qk[1].transpose(-2, -1)) * self.scale).softmax(dim=-1)
+        return attn.mean(dim=1).diagonal(dim1=-2, dim2=-1)
+
+
+class SimpleCrossAttentionRef(nn.Module):
+    """model/models.py:14-35: softmax(q(x_query) k(x_key)^T / sqrt(d)) averaged over heads -> [B, Nq, Nk]."""
+
+    def __init__(self, dim, num_heads=8):
+        super().__init__()
+        self.num_heads, self.scale = num_heads, (dim // num_heads) ** -0.5
+        self.q = nn.Linear(dim, dim, bias=True)
+        self.k = nn.Linear(dim, dim, bias=True)
+
+    def forward(self, xq, xk):
+        B, Nq, C = xq.shape
+        Nk = xk.shape[1]
+        q = self.q(xq).reshape(B, Nq, self.num_heads, C // self.num_heads).permute(0, 2, 1, 3)
+        k = self.k(xk).reshape(B, Nk, self.num_heads, C // self.num_heads).permute(0, 2, 1, 3)
+        return ((q @ k.transpose(-2, -1)) * self.scale).softmax(dim=-1).mean(dim=1)
+
+
+def saliency_scores_ref(attn_mod, t_feat, method, pre_t=2):
+    """Per-patch saliency of model/misc.py:38-165 (the quantity that is argsorted; low = kept). t_feat [B, N_t, Dt] with prefix."""
+    if method == 1:
+        return attn_mod(t_feat[:, pre_t:])
+    cls_patch = torch.cat([t_feat[:, :1], t_feat[:, pre_t:]], dim=1)
+    if method == 2:
+        B, L, D = cls_patch.shape
+        H = attn_mod.num_heads
+        q, k = torch.chunk(attn_mod.qk(cls_patch), 2, dim=-1)
+        q = q.reshape(B, L, H, D // H).permute(0, 2, 1, 3)
+        k = k.reshape(B, L, H, D // H).permute(0, 2, 1, 3)
+        attn = ((q[:, :, 0:1] @ k.transpose(-2, -1)) * (D // H) ** -0.5).softmax(dim=-1)
+        return attn.mean(dim=1).squeeze(1)[:, 1:]
+    if method == 3:
+        return attn_mod(cls_patch[:, :1], cls_patch[:, 1:]).squeeze(1)
+    raise ValueError(f"Invalid saliency masking method: {method}")
+
+
+def saliency_mgd_ref(student, s_feats, t_feats, pre_s, pre_t, ratio, method, scores=None):
+    """model/loss.py:335-360: MGD whose mask keeps the LOWEST-saliency tokens; loss = 4 * mean((G(x~) m - t m)^2)."""
+    x = student.align(s_feats[-1][:, pre_s:])
+    t = t_feats[-1]
+    if scores is None:
+        scores = saliency_scores_ref(student.saliency_attn, t, method, pre_t)
+    xg, m = _masked_generation_ref(student, x, None, ratio, scores)       # argsort(scores) plays the role of argsort(noise)
+    return F.mse_loss(xg * m, t[:, pre_t:] * m) * 4
+
+
+def attach_aux_ref(student, teacher, kind, lrkd_rank=64, saliency_method=1):
     ds, dt = student.embed_dim, teacher.embed_dim
 
     def gen():
@@ -102,6 +162,11 @@ def attach_aux_ref(student, teacher, kind, lrkd_rank=64):
         student.curkd_align_last = nn.Linear(ds, dt)
         student.mask_token = nn.Parameter(torch.zeros(1, 1, dt))
         student.generation = gen()
+    elif kind == "saliency_mgd":                            # model/models.py:129-143
+        student.align = nn.Linear(ds, dt)
+        student.mask_token = nn.Parameter(torch.zeros(1, 1, dt))
+        student.generation = gen()
+        student.saliency_attn = SimpleCrossAttentionRef(dt, 8) if saliency_method == 3 else SimpleAttentionRef(dt, 8)
     elif kind in ("soft", "hard"):
         if hasattr(student, "set_distilled_training"):
             student.set_distilled_training(True)
@@ -271,6 +336,9 @@ class DistillationLossRef(nn.Module):
             if args.wasskd_type != "l1":
                 raise NotImplementedError("sinkhorn: geomloss oracle unavailable (parity unpinned)")
             return base + 5.0 * wasskd_l1_ref(student_model, student_features, tf, ps, pt)
+        elif kind == "saliency_mgd":
+            return base + saliency_mgd_ref(student_model, student_features, tf, ps, pt, args.saliency_mask_ratio, args.saliency_method,
+                                           draws.get("scores"))
         elif kind == "vitkd":
             return base + vitkd_ref(student_model, student_features, tf, ps, pt, draws["noise"])
         elif kind == "curkd":
@@ -286,6 +354,7 @@ class DistillationLossRef(nn.Module):
 def default_args(**kw):
     a = dict(mixup=0.0, cutmix=0.0, cutmix_minmax=None, smoothing=0.1, lrkd_rank=64, lrkd_alpha=0.2, lrkd_beta=0.2,
              lrkd_gamma=0.2, wasskd_type="l1", mgd_alpha=7e-5, mgd_mask_ratio=0.5, alpha=0.1, tau=3.0,
-             distillation_type="none", current_epoch=0, amp=False, rank=0, epochs=1)
+             distillation_type="none", current_epoch=0, amp=False, rank=0, epochs=1, saliency_method=1,
+             saliency_mask_ratio=0.5)
     a.update(kw)
     return SimpleNamespace(**a)

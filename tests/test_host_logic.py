@@ -155,8 +155,8 @@ def test_state_dict_keys_are_timm_compatible():
     ref = vit_ref.VisionTransformerRef(64, 12, 1, 10, True, 0.1, **TOY)
     assert set(hip.state_dict()) == set(ref.state_dict())
     assert {k: v.shape for k, v in hip.state_dict().items()} == {k: v.shape for k, v in ref.state_dict().items()}
-    for kind in ("lrkd", "mgd", "diffkd", "wasskd", "vitkd", "curkd"):
-        a = attach_aux(vit.VisionTransformer(64, 12, 1, 10, False, 0.1, **TOY), hip, kind, SimpleNamespace(lrkd_rank=16))
+    for kind in ("lrkd", "mgd", "diffkd", "wasskd", "vitkd", "curkd", "saliency_mgd"):
+        a = attach_aux(vit.VisionTransformer(64, 12, 1, 10, False, 0.1, **TOY), hip, kind, SimpleNamespace(lrkd_rank=16, saliency_method=1))
         b = loss_ref.attach_aux_ref(vit_ref.VisionTransformerRef(64, 12, 1, 10, False, 0.1, **TOY), ref, kind, 16)
         assert {k: v.shape for k, v in a.state_dict().items()} == {k: v.shape for k, v in b.state_dict().items()}, kind
 

@@ -14,7 +14,7 @@ GOLD = os.path.join(os.path.dirname(__file__), "golden")
 TOY = dict(img_size=32, patch_size=8, mlp_ratio=2.0)
 CASES = ["none_hardlabel", "none_softlabel", "soft_softlabel", "hard_hardlabel", "lrkd_hardlabel", "lrkd_softlabel",
          "mgd_softlabel", "wasskd_softlabel", "diffkd_hardlabel", "vitkd_softlabel", "curkd_early_hardlabel", "curkd_mid_softlabel",
-         "curkd_late_softlabel"]
+         "curkd_late_softlabel", "saliency1_softlabel", "saliency2_hardlabel", "saliency3_softlabel"]
 
 
 def build(fx, tsd):
@@ -22,7 +22,7 @@ def build(fx, tsd):
     distilled = "distilled" in str(fx["student_name"])
     student = vit_ref.VisionTransformerRef(64, 12, 1, 10, distilled, 0.1, **TOY)
     teacher = vit_ref.VisionTransformerRef(128, 12, 2, 10, True, 0.1, **TOY)
-    loss_ref.attach_aux_ref(student, teacher, args.distillation_type, args.lrkd_rank)
+    loss_ref.attach_aux_ref(student, teacher, args.distillation_type, args.lrkd_rank, getattr(args, "saliency_method", 1))
     student.load_state_dict({k[8:]: torch.from_numpy(v) for k, v in fx.items() if k.startswith("student.")}, strict=True)
     teacher.load_state_dict({k[8:]: torch.from_numpy(v) for k, v in tsd.items()}, strict=True)
     return student.train(), teacher.eval(), args

@@ -40,7 +40,12 @@ __device__ __forceinline__ bf16_t f2bf(float f) {
   __bf16 b = (__bf16)f;
   return __builtin_bit_cast(bf16_t, b);
 }
-__device__ __forceinline__ uint32_t pack2bf(float lo, float hi) { return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16); }
+// one v_cvt_pk_bf16_f32 (two scalar casts + shift/or make the compiler pair the wrong elements and re-shuffle them with SDWA ops)
+typedef float dkd_f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 dkd_bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(dkd_f32x2{lo, hi}, dkd_bf16x2));
+}
 
 __device__ __forceinline__ int map_row(const DkdRowMap& m, int r) {
   return m.rpg > 0 ? (r / m.rpg) * m.gstride + (r % m.rpg) + m.off : r;

@@ -78,11 +78,12 @@ __device__ __forceinline__ EpiIn epi_prefetch(const DkdGemm& g, const int vec_ok
   }
   return in;
 }
-__device__ __forceinline__ void epi_finish(const DkdGemm& g, const int vec_ok, f32x8 v, const EpiIn& in, const int m, const int n) {
+__device__ __forceinline__ void epi_finish(const DkdGemm& g, const int vec_ok, f32x8 v, const EpiIn& in, const int m, const int n,
+                                           const bool bias_done = false) {
   const bool out_f32 = g.epi & DKD_EPI_OUT_F32;
   const size_t crow = (size_t)map_row(g.cmap, m) * g.ldc;
   if (vec_ok) {
-    if (g.epi & DKD_EPI_BIAS) {
+    if ((g.epi & DKD_EPI_BIAS) && !bias_done) {
       const f32x4 b0 = *(const f32x4*)&g.bias[n], b1 = *(const f32x4*)&g.bias[n + 4];
       v += f32x8{b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
     }
@@ -265,79 +266,113 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const DkdGemm g, const 
   nt_epilogue<BN, NJ>(g, vec_ok, smem, acc, m0, n0, tid, wr, wc);
 }
 
-// ---- 256 x 256 x 64 tile, 8 waves (2 x 4, 128 x 64 per wave), one workgroup per CU: for the wide teacher GEMMs.
-// The 128^2 kernel moves 1 B of operand from L2 into LDS per 64 FLOP and its K loop is bound by that path (main loop alone:
-// ~950 TF/s, no gain from deeper pipelines: profiles/r01_*); this tile halves the L2->LDS bytes and the LDS-DMA / ds_read
-// instructions per MFMA.
-template <int H>
-__device__ __forceinline__ void epi_pass256(const DkdGemm& g, const int vec_ok, float* cs, f32x4 (&acc)[8][4], const int m0, const int n0,
-                                            const int tid, const int wr, const int wc) {
-  const int lane = tid & 63, frow = lane & 15, fg = lane >> 4;
-  __syncthreads();
-  if (wr == (H >> 1)) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) cs[(i * 16 + fg * 4 + r) * 256 + wc * 64 + j * 16 + frow] = acc[(H & 1) * 4 + i][j][r];
+// ---- 256 x 256 tile, 8 waves (2 x 4, 128 x 64 per wave), PERSISTENT, one workgroup per CU: for the wide teacher GEMMs.
+// The 128^2 kernel moves 1 B of operand from L2 into LDS per 64 FLOP and its K loop is bound by that path; this tile halves
+// the L2->LDS bytes and the LDS-DMA / ds_read instructions per MFMA.  What the counters said about the first version of it
+// (double-buffered 64-wide K steps, profiles/r01_d_*): MFMA busy 55 %, waves 40 % of their time in s_waitcnt, LDS array 21 %
+// busy with no bank conflicts -- the loop waits for the LDS-DMA stage loads.  With 2 stage buffers at most 64 KiB per CU is
+// in flight and only right after issue; Little's law at ~2k cycles of loaded latency needs that much in flight ALL the time.
+//  * K is walked in 32-wide "units" (A half 16 KiB + W half 16 KiB, 64-B LDS rows); a ring of 5 units uses all 160 KiB of
+//    LDS: one being multiplied, four in flight (128 KiB).  Unit q+5 is issued during unit q, right after the barrier that
+//    frees q's slot, one 1-KiB piece per 8 MFMAs (an LDS-DMA instruction holds its wave's issue for 60-180 cycles; the SIMD's
+//    other wave issues MFMAs underneath); the wait is the counted vmcnt(12) = "all but the three newest units".
+//  * the ring runs across tiles: the loads of the next tile's first units are in flight during a tile's last phases and its
+//    epilogue, so there is no prologue bubble per tile and the epilogue overlaps the next tile's loads.
+//  * the fragments of the NEXT unit are read into a second register set while the MFMAs of the current one issue; every wave
+//    leaves the barrier with 32 MFMAs' operands already in registers.
+//  * the MFMA is issued with the operands swapped (acc = W-fragment x A-fragment): a lane's 4 accumulator registers are 4
+//    consecutive output COLUMNS of one row, and the W rows a fragment reads are permuted so that fragments j, j+1 hold
+//    adjacent 4-column groups -- the epilogue stores 8 consecutive columns (16 B bf16 / 2 x 16 B f32) per lane straight from
+//    registers: no LDS staging (the ring owns the LDS), no barriers, no cross-wave coupling.
+//  * 64-B LDS rows: 16-B slot s of row r sits at physical slot s ^ g[key(r)], g = {0,2,3,1}, key = (r>>2)&3 for A rows and
+//    (r>>3)&3 for W rows (= (lane>>2)&3 of the reading lane for both); every ds_read_b128 lane group then covers all 64 banks.
+struct EpiIn8 {
+  f32x4 r0, r1;
+  uint4 pre;
+};
+__device__ __forceinline__ EpiIn8 epi_prefetch8(const DkdGemm& g, const int m, const int n) {
+  EpiIn8 in;
+  in.r0 = in.r1 = f32x4{0.f, 0.f, 0.f, 0.f};
+  in.pre = uint4{0u, 0u, 0u, 0u};
+  if (g.epi & DKD_EPI_RESID) {
+    const float* rp = &g.resid[(size_t)map_row(g.rmap, m) * g.ldr + n];
+    in.r0 = *(const f32x4*)rp;
+    in.r1 = *(const f32x4*)(rp + 4);
   }
-  __syncthreads();
-  const int col8 = (tid & 31) * 8, r0 = tid >> 5;      // 32 threads per 256-column row, 16 rows per sweep
-  const int n = n0 + col8;
-  if (n >= g.N) return;
-  EpiIn in[4];
-#pragma unroll
-  for (int s = 0; s < 4; ++s) {
-    const int m = m0 + H * 64 + r0 + 16 * s;
-    if (m < g.M) in[s] = epi_prefetch(g, vec_ok, m, n);
-  }
-#pragma unroll
-  for (int s = 0; s < 4; ++s) {
-    const int rl = r0 + 16 * s;
-    const int m = m0 + H * 64 + rl;
-    if (m < g.M) {
-      const f32x4 lo = *(const f32x4*)&cs[rl * 256 + col8], hi = *(const f32x4*)&cs[rl * 256 + col8 + 4];
-      epi_finish(g, vec_ok, f32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]}, in[s], m, n);
-    }
-  }
+  if (g.epi & DKD_EPI_DGELU) in.pre = *(const uint4*)&((const bf16_t*)g.preact)[(size_t)m * g.ldp + n];
+  return in;
 }
 
-__global__ __launch_bounds__(512, 1) void gemm_nt256_kernel(const DkdGemm g, const int vec_ok) {
-  constexpr int TILE = 256 * 128;      // 32 KiB per operand tile (256 rows x 64 bf16)
-  constexpr int BUF = 2 * TILE;
-  __shared__ __attribute__((aligned(16))) char smem[2 * BUF];   // 128 KiB; the epilogue reuses 64 KiB of it
+// EOPS: vector-memory instructions one wave issues in an interior tile's epilogue when that is known at compile time (16: bf16 C
+// and nothing else), 0 otherwise.  Known, the waits that follow an epilogue count its stores as outstanding instead of draining
+// them: they retire under the next tile's first phases.
+// ABL: dev-only ablation bits (build with -DDKD_NT256_ABL=n; results are then wrong, timings are the point): 1 no epilogue,
+// 2 two units per tile, 4 no LDS-DMA in the loop, 8 no barriers, 16 no fragment reads, 32 no MFMAs.
+template <int ABL, int EOPS>
+__global__ __launch_bounds__(512, 1) void gemm_nt256_kernel(const DkdGemm g, const int n_tiles) {
+  constexpr int UNIT = 32768, WHALF = 16384, RING = 5;
+  __shared__ __attribute__((aligned(16))) char smem[RING * UNIT];   // all 160 KiB
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = w >> 2, wc = w & 3;
-  const int tiles_n = (g.N + 255) / 256;
-  const int L = xcd_remap(blockIdx.x, gridDim.x);
-  const int m0 = (L / tiles_n) * 256, n0 = (L % tiles_n) * 256;
-  const int KT = g.K / 64;
+  const int tiles_n = g.N / 256;
+  const int P = g.K / 32;               // units per tile (even: K % 64 == 0)
 
-  const bf16_t* arow[4];
-  const bf16_t* brow[4];
-  int slot[4];
+  // this block's tiles: XCD x = blockIdx % 8 owns a contiguous chunk of the tile list (its L2 sees neighbouring A panels and all
+  // of W); the chunk is dealt round-robin to the XCD's resident blocks
+  const int x = blockIdx.x & 7, slot_in_xcd = blockIdx.x >> 3, nslots = gridDim.x >> 3;
+  const int tq = n_tiles >> 3, tr = n_tiles & 7;
+  const int chunk_begin = x < tr ? x * (tq + 1) : tr * (tq + 1) + (x - tr) * tq;
+  const int chunk_cnt = tq + (x < tr ? 1 : 0);
+  const int my_tiles = slot_in_xcd < chunk_cnt ? (chunk_cnt - slot_in_xcd + nslots - 1) / nslots : 0;
+  if (my_tiles == 0) return;
+  const int total_units = my_tiles * P;
+  auto tile_of = [&](int k) { return chunk_begin + slot_in_xcd + k * nslots; };
+
+  // ---- load cursor (runs RING units ahead of the multiply cursor)
+  const bf16_t* Ab = (const bf16_t*)g.A;
+  const bf16_t* Bb = (const bf16_t*)g.B;
+  uint32_t aoff[2], boff[2];            // element offsets of this lane's 16-B source granules (< 2^31: host-checked)
+  int ld_tile = 0, ld_p = 0, ld_unit = 0;
+  auto set_load_tile = [&](int k) {
+    const int L = tile_of(k);
+    const int lm0 = (L / tiles_n) * 256, ln0 = (L % tiles_n) * 256;
 #pragma unroll
-  for (int c = 0; c < 4; ++c) {
-    const int r = w * 32 + c * 8 + (lane >> 3);
-    int m = m0 + r, n = n0 + r;
-    m = m < g.M ? m : g.M - 1;
-    n = n < g.N ? n : g.N - 1;
-    arow[c] = (const bf16_t*)g.A + (size_t)map_row(g.amap, m) * g.lda;
-    brow[c] = (const bf16_t*)g.B + (size_t)n * g.ldb;
-    slot[c] = ((lane & 7) ^ ((r >> 1) & 7)) * 8;
-  }
-  auto stage = [&](int kt) {
-    char* abase = smem + (kt & 1) * BUF;
-    char* bbase = abase + TILE;
-    const int k0 = kt * 64;
-#pragma unroll
-    for (int c = 0; c < 4; ++c)
-      __builtin_amdgcn_global_load_lds(GLB_PTR(arow[c] + k0 + slot[c]), LDS_PTR(abase + (w * 32 + c * 8) * 128), 16, 0, 0);
-#pragma unroll
-    for (int c = 0; c < 4; ++c)
-      __builtin_amdgcn_global_load_lds(GLB_PTR(brow[c] + k0 + slot[c]), LDS_PTR(bbase + (w * 32 + c * 8) * 128), 16, 0, 0);
+    for (int c = 0; c < 2; ++c) {
+      const int r = w * 32 + c * 16 + (lane >> 2);
+      int m = lm0 + r;
+      m = m < g.M ? m : g.M - 1;
+      const int ga = (0x78 >> (2 * ((r >> 2) & 3))) & 3, gw = (0x78 >> (2 * ((r >> 3) & 3))) & 3;
+      aoff[c] = (uint32_t)map_row(g.amap, m) * (uint32_t)g.lda + (((lane & 3) ^ ga) * 8);
+      boff[c] = (uint32_t)(ln0 + r) * (uint32_t)g.ldb + (((lane & 3) ^ gw) * 8);
+    }
+  };
+  set_load_tile(0);
+  // piece c (0,1: A rows w*32 + c*16 ..+15; 2,3: W rows likewise) of the load cursor's unit -> ring slot `slot`
+  // Issued through inline asm: the compiler orders every LDS read behind a pending LDS-DMA it knows of with vmcnt(0), which would
+  // drain the ring at each fragment read; ordering is this kernel's job (counted vmcnt + barrier), and the compiler's own
+  // vmcnt bookkeeping for the epilogue's loads can only over-wait because no DMA is issued between such a load and its use.
+  auto piece = [&](int c, int slot) {
+    const uint32_t dst = (uint32_t)(uintptr_t)LDS_PTR(smem) + slot * UNIT + (c >> 1) * WHALF + (w * 32 + (c & 1) * 16) * 64;
+    // SGPR base + 32-bit byte offset: half the address data of the 64-bit-per-lane form.  M0 (the LDS destination) is set inside
+    // the statement and named as a clobber; nothing else in this kernel makes the compiler use M0.
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+    const uint32_t voff = ((c < 2 ? aoff[c & 1] : boff[c & 1]) + ld_p * 32) * 2;
+    if (c < 2) asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(dst), "v"(voff), "s"(Ab) : "memory", "m0");
+    else asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(dst), "v"(voff), "s"(Bb) : "memory", "m0");
+#pragma clang diagnostic pop
+  };
+  // past the end of the block's work the cursor stays on the last unit: the re-issued pieces land in a slot nobody reads and keep
+  // the vmcnt arithmetic uniform
+  auto advance_load = [&]() {
+    if (ld_unit + 1 < total_units) {
+      ++ld_unit;
+      if (++ld_p == P) {
+        ld_p = 0;
+        set_load_tile(++ld_tile);
+      }
+    }
   };
 
   f32x4 acc[8][4];
@@ -345,36 +380,134 @@ __global__ __launch_bounds__(512, 1) void gemm_nt256_kernel(const DkdGemm g, con
   for (int i = 0; i < 8; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const int frow = lane & 15, fg = lane >> 4, fswz = (frow >> 1) & 7;
+  const int frow = lane & 15, fg = lane >> 4;
+  const int phys = fg ^ ((0x78 >> (2 * ((frow >> 2) & 3))) & 3);
+  const int a_lds = (wr * 128 + frow) * 64 + phys * 16;
+  const int w_lds = WHALF + (wc * 64 + 8 * (frow >> 2) + (frow & 3)) * 64 + phys * 16;
 
-  stage(0);
-  for (int kt = 0; kt < KT; ++kt) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    if (kt + 1 < KT) stage(kt + 1);
-    const char* abase = smem + (kt & 1) * BUF;
-    const char* bbase = abase + TILE;
+  // A fragments are refreshed IN PLACE: a[i] is dead once its 4 MFMAs have issued, so the next unit's fragment i is read into
+  // it right behind them (96 -> 64 fragment registers; a second full set spilled).  W fragments (used by every i) have two sets.
+  bf16x8 a[8], bF[4], bG[4];
+  auto lda_frag = [&](const int i, const int slot) { a[i] = *(const bf16x8*)(smem + slot * UNIT + a_lds + i * 1024); };
+  auto ldb_frag = [&](bf16x8 (&b)[4], const int slot) {
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      const int ps = ((kk * 4 + fg) ^ fswz) * 16;
-      bf16x8 a[8], b[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) b[j] = *(const bf16x8*)(bbase + (wc * 64 + j * 16 + frow) * 128 + ps);
-#pragma unroll
-      for (int i = 0; i < 8; ++i) a[i] = *(const bf16x8*)(abase + (wr * 128 + i * 16 + frow) * 128 + ps);
-      __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-      for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
-      __builtin_amdgcn_s_setprio(0);
+    for (int j = 0; j < 4; ++j) b[j] = *(const bf16x8*)(smem + slot * UNIT + w_lds + (j >> 1) * 2048 + (j & 1) * 256);
+  };
+
+  int slot = 0;                         // ring slot of the unit being multiplied
+  int pend = 0;                         // phases left in which the previous epilogue's stores may be outstanding
+  bool exact = false;                   // the previous epilogue issued exactly EOPS instructions in every wave
+  // one unit: a[] and X hold its fragments (already waited for); a[] and Y receive the next unit's (not across a tile boundary:
+  // the epilogue needs the registers)
+  auto phase = [&](const bf16x8 (&X)[4], bf16x8 (&Y)[4], const bool last_of_tile) {
+    // my pieces of the next unit have landed: all but the three newest units (12 pieces) -- plus, in the first three phases after
+    // an epilogue with a known instruction count, its stores (they sit between those units in the in-order counter)
+    if (EOPS > 0 && pend > 0) {
+      static_assert(EOPS == 0 || EOPS == 16, "encode vmcnt(12 + EOPS) below");
+      __builtin_amdgcn_s_waitcnt(0x4F7C);   // vmcnt(28)
+      --pend;
+    } else {
+      __builtin_amdgcn_s_waitcnt(0x0F7C);   // vmcnt(12)
     }
+    if (!(ABL & 8)) __builtin_amdgcn_s_barrier();         // ... and everybody's; and everybody is done reading this unit's slot
+    __builtin_amdgcn_sched_barrier(0);
+    const int nslot = slot == RING - 1 ? 0 : slot + 1;
+    if (!last_of_tile && !(ABL & 16)) ldb_frag(Y, nslot);
+    // One LDS-DMA piece per 8 MFMAs, every wave at the same points.  (Tried: each wave at its own MFMA slot so that at most one
+    // wave of the CU is in a DMA issue -- 25 % slower; all four pieces in a burst behind the barrier -- the same.  In shader
+    // cycles this loop already runs at the rate of its LDS-DMA stream alone: DESIGN.md, 'wide NT kernel'.)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (!(ABL & 32)) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(X[j], a[i], acc[i][j], 0, 0, 0);
+      if (!last_of_tile && !(ABL & 16)) lda_frag(i, nslot);
+      if (!last_of_tile && !(ABL & 4) && (i & 1)) piece(i >> 1, slot);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (!last_of_tile) advance_load();
+    __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): the next unit's fragments arrived under these MFMAs
+  };
+
+  for (int u = 0; u < RING; ++u) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) piece(c, u);
+    advance_load();
   }
-  float* cs = (float*)smem;
-  epi_pass256<0>(g, vec_ok, cs, acc, m0, n0, tid, wr, wc);
-  epi_pass256<1>(g, vec_ok, cs, acc, m0, n0, tid, wr, wc);
-  epi_pass256<2>(g, vec_ok, cs, acc, m0, n0, tid, wr, wc);
-  epi_pass256<3>(g, vec_ok, cs, acc, m0, n0, tid, wr, wc);
+
+  for (int k = 0; k < my_tiles; ++k) {
+    // ---- tile prologue: the tile's first unit has landed.  Outstanding in the in-order counter at this point: 4 units, the
+    // previous tile's epilogue stores, and the unit issued after them -> "all but the newest unit" (k > 0), which over-waits by
+    // the stores' acknowledge; 16 pieces ahead on the very first tile.
+    if (k == 0) __builtin_amdgcn_s_waitcnt(0x4F70);   // vmcnt(16)
+    else if (EOPS > 0 && exact) __builtin_amdgcn_s_waitcnt(0x8F70);   // vmcnt(16 + 16): 3 units + the stores + the newest unit
+    else __builtin_amdgcn_s_waitcnt(0x0F74);          // vmcnt(4)
+    pend = (EOPS > 0 && exact && k > 0) ? 3 : 0;
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    ldb_frag(bF, slot);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) lda_frag(i, slot);
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    for (int p = 0; p < ((ABL & 2) ? 2 : P); p += 2) {
+      phase(bF, bG, false);
+      slot = slot == RING - 1 ? 0 : slot + 1;
+      phase(bG, bF, p + 2 >= P);
+      // (the slot of a tile's last unit is refilled after the epilogue, below)
+      if (p + 2 < P) slot = slot == RING - 1 ? 0 : slot + 1;
+    }
+    // ---- epilogue, straight from registers: lane holds C[m0 + wr*128 + i*16 + frow][n0 + wc*64 + 32*jp + 8*fg .. +7]
+    const int L = tile_of(k);
+    const int m0 = (L / tiles_n) * 256, n0 = (L % tiles_n) * 256;
+    exact = m0 + 256 <= g.M;              // no row of the tile is masked off: every wave issues all its stores
+    if (ABL & 1) {
+      float t = 0.f;
+      for (int i = 0; i < 8; ++i)
+        for (int j = 0; j < 4; ++j) t += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+      if (t == 1234.5f) ((float*)g.C)[0] = t;
+    } else {
+      const int nb = n0 + wc * 64 + fg * 8;
+      f32x8 bias8[2];                    // in registers: C may alias anything, so the compiler would reload it per vector
+#pragma unroll
+      for (int jp = 0; jp < 2; ++jp) {
+        bias8[jp] = f32x8{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (g.epi & DKD_EPI_BIAS) {
+          const f32x4 b0 = *(const f32x4*)&g.bias[nb + jp * 32], b1 = *(const f32x4*)&g.bias[nb + jp * 32 + 4];
+          bias8[jp] = f32x8{b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int m = m0 + wr * 128 + i * 16 + frow;
+        if (m < g.M) {
+          EpiIn in[2];
+#pragma unroll
+          for (int jp = 0; jp < 2; ++jp) in[jp] = epi_prefetch(g, 1, m, nb + jp * 32);
+#pragma unroll
+          for (int jp = 0; jp < 2; ++jp) {
+            const f32x4 lo = acc[i][2 * jp], hi = acc[i][2 * jp + 1];
+            if (EOPS == 16 && !(g.epi & ~DKD_EPI_BIAS)) {
+              // bias-only bf16 output (qkv): streaming store -- the 230 MB output is not re-read from L2
+              typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+              const uint4 pk = pack8(f32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]} + bias8[jp]);
+              __builtin_nontemporal_store(u32x4{pk.x, pk.y, pk.z, pk.w}, (u32x4*)((bf16_t*)g.C + (size_t)m * g.ldc + nb + jp * 32));
+            } else
+            epi_finish(g, 1, f32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]} + bias8[jp], in[jp], m, nb + jp * 32, true);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // refill the slot the tile's last unit occupied (every wave passed that unit's barrier long ago... but not its READS: the
+    // last phase's fragment reads were of the NEXT slot; this slot's reads completed before the last phase's barrier)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) piece(c, slot);
+    advance_load();
+    slot = slot == RING - 1 ? 0 : slot + 1;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ TN (wgrad)
@@ -768,10 +901,30 @@ extern "C" int dkd_gemm_nt(const DkdGemm* gp, void* stream) {
   const bool narrow = (g.N % 128 != 0) && (g.N % 128 <= 64);
   const int tiles_m = cdiv(g.M, BM);
   // wide GEMMs with enough 256^2 tiles to keep 256 CUs balanced (>= 4 rounds): qkv / fc1 of the teacher
-  const bool wide = g.N % 256 == 0 && (long)cdiv(g.M, 256) * (g.N / 256) >= 1024;
+  const long a_last = g.amap.rpg > 0 ? (long)((g.M - 1) / g.amap.rpg) * g.amap.gstride + (g.M - 1) % g.amap.rpg + g.amap.off : g.M - 1;
+  const bool fits32 = (a_last + 1) * g.lda < (1L << 31) && (long)g.N * g.ldb < (1L << 31);   // its 32-bit source offsets
+  const bool wide = vec_ok && fits32 && g.N % 256 == 0 && g.K >= 320 && (long)cdiv(g.M, 256) * (g.N / 256) >= 1024;
   ProbeScope probe(wide ? 2 : (narrow ? 1 : 0), 2.0 * g.M * g.N * g.K, as_stream(stream));
   if (wide) {
-    hipLaunchKernelGGL(gemm_nt256_kernel, dim3(cdiv(g.M, 256) * (g.N / 256)), dim3(512), 0, as_stream(stream), g, vec_ok);
+    static int n_cu = 0;
+    if (!n_cu) {
+      int dev = 0;
+      hipDeviceProp_t prop;
+      if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) {
+        dkd_set_error("gemm_nt: cannot query the device");
+        return DKD_ERR_HIP;
+      }
+      n_cu = prop.multiProcessorCount & ~7;
+    }
+    const int n_tiles = cdiv(g.M, 256) * (g.N / 256);
+    const dim3 grid(n_cu);             // persistent: one workgroup per CU, tiles dealt per XCD inside the kernel
+    // bf16 C and nothing else written or read by the epilogue: 16 stores per wave per tile, counted exactly by the waits
+    const bool plain16 = !(g.epi & (DKD_EPI_RESID | DKD_EPI_DGELU | DKD_EPI_OUT_F32)) && !g.tap && !g.preact;
+#ifndef DKD_NT256_ABL
+#define DKD_NT256_ABL 0
+#endif
+    if (plain16) hipLaunchKernelGGL((gemm_nt256_kernel<DKD_NT256_ABL, 16>), grid, dim3(512), 0, as_stream(stream), g, n_tiles);
+    else hipLaunchKernelGGL((gemm_nt256_kernel<DKD_NT256_ABL, 0>), grid, dim3(512), 0, as_stream(stream), g, n_tiles);
     DKD_CHECK_LAUNCH("gemm_nt256");
     return DKD_OK;
   }

@@ -6,6 +6,8 @@ semantics, statement for statement.  Differences, all hos
   * ``forward_with_features`` works through a data-parallel wrapper.
 The loop itself is model-agnostic: any nn.Module student/teacher and any criterion with the reference's call contract work.
 """
+import os
+
 import torch
 
 from .logger import MetricLogger
@@ -19,12 +21,31 @@ def train_one_epoch(student_model, teacher_model, train_loader, criterion, optim
     teacher_model.eval()
     metric_logger = MetricLogger()
     header = f'Epoch: [{epoch+1}/{args.epochs}]'
-    for samples, targets in metric_logger.log_every(train_loader, getattr(args, "print_freq", 10), header, getattr(args, "rank", 0)):
+    batches = iter(metric_logger.log_every(train_loader, getattr(args, "print_freq", 10), header, getattr(args, "rank", 0)))
+
+    def fetch():
+        try:
+            samples, targets = next(batches)
+        except StopIteration:
+            return None
+        original_targets = None
         if mixup_fn is not None:
             original_targets = targets.to(device, non_blocking=True)
             samples, targets = mixup_fn(samples, targets)
-        samples = samples.to(device, non_blocking=True)
-        targets = targets.to(device, non_blocking=True)
+        return samples.to(device, non_blocking=True), targets.to(device, non_blocking=True), original_targets
+
+    # One batch of lookahead, so that a criterion with a ``prefetch`` hook (deltakd_amd.losses.DistillationLoss) can start the
+    # frozen teacher on batch t+1 while the student's backward of batch t runs.  Batches, mixup draws (numpy RNG) and the
+    # student's torch RNG draws keep their order, so the step computes what the statement-for-statement loop computes.
+    prefetch = getattr(criterion, "prefetch", None)
+    if args.distillation_type.lower() == "none" or os.environ.get("DKD_NO_LOOKAHEAD"):
+        prefetch = None                  # nothing to start early: keep the plain order (next batch fetched after the step)
+    args.current_epoch = epoch
+    nxt = fetch()
+    if nxt is not None and prefetch is not None:
+        prefetch(nxt[0], args)
+    while nxt is not None:
+        samples, targets, original_targets = nxt
 
         # --amp only ever wrapped the student forward in the reference (tools/engine.py:23-34); the HIP path already computes
         # in bf16 with fp32 accumulation, so the flag changes nothing here.
@@ -34,8 +55,12 @@ def train_one_epoch(student_model, teacher_model, train_loader, criterion, optim
         else:
             student_logits, student_feats = forward_with_features(student_model, samples)
 
-        args.current_epoch = epoch
         loss = criterion(samples, student_logits, student_model, student_feats, targets, args)
+
+        if prefetch is not None:
+            nxt = fetch()
+            if nxt is not None:
+                prefetch(nxt[0], args)
 
         if not isinstance(student_logits, torch.Tensor):
             student_logits, _ = student_logits
@@ -55,6 +80,8 @@ def train_one_epoch(student_model, teacher_model, train_loader, criterion, optim
         metric_logger.update(train_acc1=acc1.detach())
         metric_logger.update(train_acc5=acc5.detach())
         metric_logger.update(train_lr=optimizer.param_groups[0]['lr'])
+        if prefetch is None:
+            nxt = fetch()
     return {k: meter.global_avg for k, meter in metric_logger.meters.items()}
 
 

@@ -286,36 +286,27 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const DkdGemm g, const 
 //    registers: no LDS staging (the ring owns the LDS), no barriers, no cross-wave coupling.
 //  * 64-B LDS rows: 16-B slot s of row r sits at physical slot s ^ g[key(r)], g = {0,2,3,1}, key = (r>>2)&3 for A rows and
 //    (r>>3)&3 for W rows (= (lane>>2)&3 of the reading lane for both); every ds_read_b128 lane group then covers all 64 banks.
-struct EpiIn8 {
-  f32x4 r0, r1;
-  uint4 pre;
-};
-__device__ __forceinline__ EpiIn8 epi_prefetch8(const DkdGemm& g, const int m, const int n) {
-  EpiIn8 in;
-  in.r0 = in.r1 = f32x4{0.f, 0.f, 0.f, 0.f};
-  in.pre = uint4{0u, 0u, 0u, 0u};
-  if (g.epi & DKD_EPI_RESID) {
-    const float* rp = &g.resid[(size_t)map_row(g.rmap, m) * g.ldr + n];
-    in.r0 = *(const f32x4*)rp;
-    in.r1 = *(const f32x4*)(rp + 4);
-  }
-  if (g.epi & DKD_EPI_DGELU) in.pre = *(const uint4*)&((const bf16_t*)g.preact)[(size_t)m * g.ldp + n];
-  return in;
-}
-
 // EOPS: vector-memory instructions one wave issues in an interior tile's epilogue when that is known at compile time (16: bf16 C
 // and nothing else), 0 otherwise.  Known, the waits that follow an epilogue count its stores as outstanding instead of draining
 // them: they retire under the next tile's first phases.
 // ABL: dev-only ablation bits (build with -DDKD_NT256_ABL=n; results are then wrong, timings are the point): 1 no epilogue,
 // 2 two units per tile, 4 no LDS-DMA in the loop, 8 no barriers, 16 no fragment reads, 32 no MFMAs.
-template <int ABL, int EOPS>
-__global__ __launch_bounds__(512, 1) void gemm_nt256_kernel(const DkdGemm g, const int n_tiles) {
-  constexpr int UNIT = 32768, WHALF = 16384, RING = 5;
-  __shared__ __attribute__((aligned(16))) char smem[RING * UNIT];   // all 160 KiB
+// WN: waves along N.  4: the 256 x 256 tile, 8 waves, ring of 5 units, one workgroup per CU (qkv / fc1 of the teacher).
+//     2: a 256 x 128 tile, 4 waves, ring of 3 units (72 KiB), two workgroups per CU -- for N = 768 (proj / fc2), where 256-wide
+//        tiles leave 256 CUs with 2.3 rounds of work; it moves 25 % less operand data through the LDS-DMA path than the
+//        128 x 128 kernel, and the second workgroup computes while the first one's f32 residual epilogue drains.
+constexpr uint32_t vmcnt_imm(int n) { return (uint32_t)((n & 15) | ((n >> 4) << 14) | 0x0F70); }   // s_waitcnt vmcnt(n) only
+template <int ABL, int EOPS, int WN>
+__global__ __launch_bounds__(128 * WN, WN == 4 ? 1 : 2) void gemm_nt256_kernel(const DkdGemm g, const int n_tiles) {
+  constexpr int BN = 64 * WN, NW = 2 * WN;          // tile columns, waves
+  constexpr int WHALF = 16384, UNIT = WHALF + BN * 64, RING = WN == 4 ? 5 : 3;
+  constexpr int AP = 8 / WN, PIECES = AP + 2;       // 1-KiB LDS-DMA pieces per wave per unit: A rows, then 2 of W rows
+  static_assert(EOPS == 0 || (EOPS == 16 && WN == 4), "the counted waits below encode 12 + 16 and 16 + 16");
+  __shared__ __attribute__((aligned(16))) char smem[RING * UNIT];   // WN = 4: all 160 KiB
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wr = w >> 2, wc = w & 3;
-  const int tiles_n = g.N / 256;
+  const int wr = w / WN, wc = w % WN;
+  const int tiles_n = g.N / BN;
   const int P = g.K / 32;               // units per tile (even: K % 64 == 0)
 
   // this block's tiles: XCD x = blockIdx % 8 owns a contiguous chunk of the tile list (its L2 sees neighbouring A panels and all
@@ -332,34 +323,41 @@ __global__ __launch_bounds__(512, 1) void gemm_nt256_kernel(const DkdGemm g, con
   // ---- load cursor (runs RING units ahead of the multiply cursor)
   const bf16_t* Ab = (const bf16_t*)g.A;
   const bf16_t* Bb = (const bf16_t*)g.B;
-  uint32_t aoff[2], boff[2];            // element offsets of this lane's 16-B source granules (< 2^31: host-checked)
+  uint32_t aoff[AP], boff[2];           // element offsets of this lane's 16-B source granules (< 2^31: host-checked)
   int ld_tile = 0, ld_p = 0, ld_unit = 0;
   auto set_load_tile = [&](int k) {
     const int L = tile_of(k);
-    const int lm0 = (L / tiles_n) * 256, ln0 = (L % tiles_n) * 256;
+    const int lm0 = (L / tiles_n) * 256, ln0 = (L % tiles_n) * BN;
+#pragma unroll
+    for (int c = 0; c < AP; ++c) {
+      const int r = w * (256 / NW) + c * 16 + (lane >> 2);
+      int m = lm0 + r;
+      m = m < g.M ? m : g.M - 1;
+      const int ga = (0x78 >> (2 * ((r >> 2) & 3))) & 3;
+      aoff[c] = (uint32_t)map_row(g.amap, m) * (uint32_t)g.lda + (((lane & 3) ^ ga) * 8);
+    }
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
       const int r = w * 32 + c * 16 + (lane >> 2);
-      int m = lm0 + r;
-      m = m < g.M ? m : g.M - 1;
-      const int ga = (0x78 >> (2 * ((r >> 2) & 3))) & 3, gw = (0x78 >> (2 * ((r >> 3) & 3))) & 3;
-      aoff[c] = (uint32_t)map_row(g.amap, m) * (uint32_t)g.lda + (((lane & 3) ^ ga) * 8);
+      const int gw = (0x78 >> (2 * ((r >> 3) & 3))) & 3;
       boff[c] = (uint32_t)(ln0 + r) * (uint32_t)g.ldb + (((lane & 3) ^ gw) * 8);
     }
   };
   set_load_tile(0);
-  // piece c (0,1: A rows w*32 + c*16 ..+15; 2,3: W rows likewise) of the load cursor's unit -> ring slot `slot`
+  // piece c of the load cursor's unit -> ring slot `slot`.  c < AP: A rows w*(256/NW) + c*16 ..+15; then two pieces of W rows.
   // Issued through inline asm: the compiler orders every LDS read behind a pending LDS-DMA it knows of with vmcnt(0), which would
   // drain the ring at each fragment read; ordering is this kernel's job (counted vmcnt + barrier), and the compiler's own
   // vmcnt bookkeeping for the epilogue's loads can only over-wait because no DMA is issued between such a load and its use.
   auto piece = [&](int c, int slot) {
-    const uint32_t dst = (uint32_t)(uintptr_t)LDS_PTR(smem) + slot * UNIT + (c >> 1) * WHALF + (w * 32 + (c & 1) * 16) * 64;
+    const bool is_a = c < AP;
+    const int row0 = is_a ? w * (256 / NW) + c * 16 : w * 32 + (c - AP) * 16;
+    const uint32_t dst = (uint32_t)(uintptr_t)LDS_PTR(smem) + slot * UNIT + (is_a ? 0 : WHALF) + row0 * 64;
     // SGPR base + 32-bit byte offset: half the address data of the 64-bit-per-lane form.  M0 (the LDS destination) is set inside
     // the statement and named as a clobber; nothing else in this kernel makes the compiler use M0.
+    const uint32_t voff = ((is_a ? aoff[is_a ? c : 0] : boff[is_a ? 0 : c - AP]) + ld_p * 32) * 2;
 #pragma clang diagnostic push
 #pragma clang diagnostic ignored "-Winline-asm"
-    const uint32_t voff = ((c < 2 ? aoff[c & 1] : boff[c & 1]) + ld_p * 32) * 2;
-    if (c < 2) asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(dst), "v"(voff), "s"(Ab) : "memory", "m0");
+    if (is_a) asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(dst), "v"(voff), "s"(Ab) : "memory", "m0");
     else asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(dst), "v"(voff), "s"(Bb) : "memory", "m0");
 #pragma clang diagnostic pop
   };
@@ -383,7 +381,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt256_kernel(const DkdGemm g, con
   const int frow = lane & 15, fg = lane >> 4;
   const int phys = fg ^ ((0x78 >> (2 * ((frow >> 2) & 3))) & 3);
   const int a_lds = (wr * 128 + frow) * 64 + phys * 16;
-  const int w_lds = WHALF + (wc * 64 + 8 * (frow >> 2) + (frow & 3)) * 64 + phys * 16;
+  const int w_lds = WHALF + (wc * 64 + 8 * (frow >> 2) + (frow & 3)) * 64 + phys * 16;   // wr in {0,1}, wc < WN
 
   // A fragments are refreshed IN PLACE: a[i] is dead once its 4 MFMAs have issued, so the next unit's fragment i is read into
   // it right behind them (96 -> 64 fragment registers; a second full set spilled).  W fragments (used by every i) have two sets.
@@ -400,20 +398,19 @@ __global__ __launch_bounds__(512, 1) void gemm_nt256_kernel(const DkdGemm g, con
   // one unit: a[] and X hold its fragments (already waited for); a[] and Y receive the next unit's (not across a tile boundary:
   // the epilogue needs the registers)
   auto phase = [&](const bf16x8 (&X)[4], bf16x8 (&Y)[4], const bool last_of_tile) {
-    // my pieces of the next unit have landed: all but the three newest units (12 pieces) -- plus, in the first three phases after
-    // an epilogue with a known instruction count, its stores (they sit between those units in the in-order counter)
+    // my pieces of the next unit have landed: all but the RING-2 newest units -- plus, in the first RING-2 phases after an
+    // epilogue with a known instruction count, its stores (they sit between those units in the in-order counter)
     if (EOPS > 0 && pend > 0) {
-      static_assert(EOPS == 0 || EOPS == 16, "encode vmcnt(12 + EOPS) below");
-      __builtin_amdgcn_s_waitcnt(0x4F7C);   // vmcnt(28)
+      __builtin_amdgcn_s_waitcnt(vmcnt_imm((RING - 2) * PIECES + EOPS));
       --pend;
     } else {
-      __builtin_amdgcn_s_waitcnt(0x0F7C);   // vmcnt(12)
+      __builtin_amdgcn_s_waitcnt(vmcnt_imm((RING - 2) * PIECES));
     }
     if (!(ABL & 8)) __builtin_amdgcn_s_barrier();         // ... and everybody's; and everybody is done reading this unit's slot
     __builtin_amdgcn_sched_barrier(0);
     const int nslot = slot == RING - 1 ? 0 : slot + 1;
     if (!last_of_tile && !(ABL & 16)) ldb_frag(Y, nslot);
-    // One LDS-DMA piece per 8 MFMAs, every wave at the same points.  (Tried: each wave at its own MFMA slot so that at most one
+    // One LDS-DMA piece per 8 (WN = 4) or ~5 (WN = 2) MFMAs, every wave at the same points.  (Tried: each wave at its own MFMA slot so that at most one
     // wave of the CU is in a DMA issue -- 25 % slower; all four pieces in a burst behind the barrier -- the same.  In shader
     // cycles this loop already runs at the rate of its LDS-DMA stream alone: DESIGN.md, 'wide NT kernel'.)
 #pragma unroll
@@ -422,7 +419,10 @@ __global__ __launch_bounds__(512, 1) void gemm_nt256_kernel(const DkdGemm g, con
       for (int j = 0; j < 4; ++j)
         if (!(ABL & 32)) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(X[j], a[i], acc[i][j], 0, 0, 0);
       if (!last_of_tile && !(ABL & 16)) lda_frag(i, nslot);
-      if (!last_of_tile && !(ABL & 4) && (i & 1)) piece(i >> 1, slot);
+      // PIECES = 4: after row groups 1,3,5,7;  6: after 0,1,3,4,5,7
+      const bool issue_here = PIECES == 4 ? (i & 1) : (i % 4 != 2);      // (constants once the loop is unrolled)
+      const int which = PIECES == 4 ? (i >> 1) : (i - (i > 2) - (i > 6));
+      if (issue_here && !last_of_tile && !(ABL & 4)) piece(which, slot);
       __builtin_amdgcn_sched_barrier(0);
     }
     if (!last_of_tile) advance_load();
@@ -431,18 +431,18 @@ __global__ __launch_bounds__(512, 1) void gemm_nt256_kernel(const DkdGemm g, con
 
   for (int u = 0; u < RING; ++u) {
 #pragma unroll
-    for (int c = 0; c < 4; ++c) piece(c, u);
+    for (int c = 0; c < PIECES; ++c) piece(c, u);
     advance_load();
   }
 
   for (int k = 0; k < my_tiles; ++k) {
-    // ---- tile prologue: the tile's first unit has landed.  Outstanding in the in-order counter at this point: 4 units, the
+    // ---- tile prologue: the tile's first unit has landed.  Outstanding in the in-order counter at this point: RING-1 units, the
     // previous tile's epilogue stores, and the unit issued after them -> "all but the newest unit" (k > 0), which over-waits by
-    // the stores' acknowledge; 16 pieces ahead on the very first tile.
-    if (k == 0) __builtin_amdgcn_s_waitcnt(0x4F70);   // vmcnt(16)
-    else if (EOPS > 0 && exact) __builtin_amdgcn_s_waitcnt(0x8F70);   // vmcnt(16 + 16): 3 units + the stores + the newest unit
-    else __builtin_amdgcn_s_waitcnt(0x0F74);          // vmcnt(4)
-    pend = (EOPS > 0 && exact && k > 0) ? 3 : 0;
+    // the stores' acknowledge unless their number is known; RING-1 units ahead on the very first tile.
+    if (k == 0) __builtin_amdgcn_s_waitcnt(vmcnt_imm((RING - 1) * PIECES));
+    else if (EOPS > 0 && exact) __builtin_amdgcn_s_waitcnt(vmcnt_imm((RING - 1) * PIECES + EOPS));   // RING-2 units + the stores + the newest unit
+    else __builtin_amdgcn_s_waitcnt(vmcnt_imm(PIECES));
+    pend = (EOPS > 0 && exact && k > 0) ? RING - 2 : 0;
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     ldb_frag(bF, slot);
@@ -458,7 +458,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt256_kernel(const DkdGemm g, con
     }
     // ---- epilogue, straight from registers: lane holds C[m0 + wr*128 + i*16 + frow][n0 + wc*64 + 32*jp + 8*fg .. +7]
     const int L = tile_of(k);
-    const int m0 = (L / tiles_n) * 256, n0 = (L % tiles_n) * 256;
+    const int m0 = (L / tiles_n) * 256, n0 = (L % tiles_n) * BN;
     exact = m0 + 256 <= g.M;              // no row of the tile is masked off: every wave issues all its stores
     if (ABL & 1) {
       float t = 0.f;
@@ -504,7 +504,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt256_kernel(const DkdGemm g, con
     // refill the slot the tile's last unit occupied (every wave passed that unit's barrier long ago... but not its READS: the
     // last phase's fragment reads were of the NEXT slot; this slot's reads completed before the last phase's barrier)
 #pragma unroll
-    for (int c = 0; c < 4; ++c) piece(c, slot);
+    for (int c = 0; c < PIECES; ++c) piece(c, slot);
     advance_load();
     slot = slot == RING - 1 ? 0 : slot + 1;
   }
@@ -816,6 +816,223 @@ __global__ __launch_bounds__(256, 2) void gemm_tn192_kernel(const bf16_t* __rest
   }
 }
 
+// ---- 128 x 192 wgrad tile fed by an LDS-DMA ring.
+// The register-staged kernel above runs one 64-row k step per ~4 us: its loads are issued one step ahead (the registers hold no
+// more) and HBM latency under load is several times a step's 0.4 us of MFMA work, so two co-resident workgroups leave the CU idle
+// most of the time (main loop alone: 2 TB/s of operand reads).  Here the operands go HBM -> LDS by global_load_lds in 32-row
+// units through a ring of four (80 KiB per workgroup, two workgroups per CU); three units are in flight behind the one being
+// multiplied, and the waits are counted vmcnt as in the wide NT kernel.
+//  * LDS-DMA writes 1 KiB linearly, so rows cannot be padded; 32-B granules are XOR-swizzled instead: A rows (256 B, 8 granules):
+//    granule ^ (row & 7); B rows (384 B, 12 granules): within each group of four, (granule & 3) ^ ((row >> 1) & 3).  Both make the
+//    8 rows a ds_read_b64_tr_b16 lane group touches fall on 8 distinct 8-bank sets.  The swizzle is applied to the per-lane SOURCE
+//    address of the DMA and to the fragment read address.
+//  * rows past M and columns past N1 / N2 are sourced from a 16-byte page of zeros.
+//  * the fused bias gradient (column sums of dY) is one more MFMA per row tile against a fragment of ones.
+__device__ uint4 dkd_zero16 = {0u, 0u, 0u, 0u};
+
+template <bool SWAP>
+__global__ __launch_bounds__(256, 2) void gemm_tn192d_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, float* C, int M,
+                                                             int N1, int N2, int lda, int ldb, int ldc, DkdRowMap amap, DkdRowMap bmap,
+                                                             int units_per_split, float* __restrict__ colsum, int tiles1) {
+  constexpr int A_ST = 32 * 256, UNIT = A_ST + 32 * 384, RING = 4, PIECES = 5;   // per wave: 2 pieces of A, 3 of B
+  constexpr int SMEM = RING * UNIT;                                              // 80 KiB; the epilogue reuses 49 KiB of it
+  static_assert(SMEM >= 64 * T192_CS * 4, "epilogue staging must fit");
+  __shared__ __attribute__((aligned(16))) char smem[SMEM];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = w >> 1, wc = w & 1;
+  // 1-D grid, XCD-aware: each XCD gets a contiguous run of (split, tile) ids with the tiles of a split adjacent, so the blocks
+  // that stream the same rows of the 192-wide operand run on the same XCD at the same time and share them through its L2
+  // (dealt round-robin, every XCD fetched those rows again: twice the HBM/fabric traffic for a 768 x 192 gradient)
+  const int L = xcd_remap(blockIdx.x, gridDim.x);
+  const int tile = L % tiles1, split = L / tiles1;
+  const int n1_0 = tile * 128;
+  const int U_all = (M + 31) / 32;
+  const int u_begin = split * units_per_split;
+  const int u_end = min(U_all, u_begin + units_per_split);
+  if (u_begin >= u_end) return;
+  const int n_units = u_end - u_begin;
+
+  // ---- per-lane DMA sources.  piece c < 2: A piece w*2 + c (4 rows x 256 B each); else B piece w*3 + (c-2) (1 KiB of 384-B rows)
+  int prow[PIECES], pcol[PIECES];        // row inside the unit, source column (elements); pcol < 0: zero page
+#pragma unroll
+  for (int c = 0; c < PIECES; ++c) {
+    if (c < 2) {
+      const int off = (w * 2 + c) * 1024 + lane * 16;
+      const int row = off >> 8, p = (off >> 4) & 15;
+      const int g = (p >> 1) ^ (row & 7);
+      const int col = n1_0 + g * 16 + (p & 1) * 8;
+      prow[c] = row;
+      pcol[c] = col < N1 ? col : -1;
+    } else {
+      const int off = (w * 3 + (c - 2)) * 1024 + lane * 16;
+      const int row = off / 384, cb = off % 384;
+      const int G = cb >> 5;
+      const int g = (G & ~3) | ((G & 3) ^ ((row >> 1) & 3));
+      const int col = g * 16 + ((cb >> 4) & 1) * 8;
+      prow[c] = row;
+      pcol[c] = col < N2 ? col : -1;
+    }
+  }
+  // mapped source row of each piece for the load cursor's unit, advanced incrementally (no division per unit)
+  int mrow[PIECES], mgrp[PIECES];
+  auto seek = [&](int c, int m) {        // m -> (group, row in group) of the operand's row map
+    const DkdRowMap& mp = c < 2 ? amap : bmap;
+    if (mp.rpg > 0) {
+      mgrp[c] = m / mp.rpg;
+      mrow[c] = m % mp.rpg;
+    } else {
+      mgrp[c] = 0;
+      mrow[c] = m;
+    }
+  };
+#pragma unroll
+  for (int c = 0; c < PIECES; ++c) seek(c, u_begin * 32 + prow[c]);
+  int ld_u = 0;                          // load cursor (unit index inside this block's range)
+  const bf16_t* zero = (const bf16_t*)&dkd_zero16;
+  auto piece = [&](int c, int slot) {
+    const DkdRowMap& mp = c < 2 ? amap : bmap;
+    const int m = (u_begin + ld_u) * 32 + prow[c];
+    const long srow = mp.rpg > 0 ? (long)mgrp[c] * mp.gstride + mrow[c] + mp.off : (long)mrow[c];
+    const bf16_t* base = c < 2 ? A : B;
+    const int ld = c < 2 ? lda : ldb;
+    const bf16_t* src = (pcol[c] >= 0 && m < M) ? base + srow * ld + pcol[c] : zero;
+    const uint32_t dst = (uint32_t)(uintptr_t)LDS_PTR(smem) + slot * UNIT + (c < 2 ? (w * 2 + c) * 1024 : A_ST + (w * 3 + (c - 2)) * 1024);
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(dst), "v"(src) : "memory", "m0");
+#pragma clang diagnostic pop
+  };
+  auto advance_load = [&]() {            // past the end the cursor stays: re-issued pieces land in a free slot nobody reads
+    if (ld_u + 1 < n_units) {
+      ++ld_u;
+#pragma unroll
+      for (int c = 0; c < PIECES; ++c) {
+        const DkdRowMap& mp = c < 2 ? amap : bmap;
+        mrow[c] += 32;
+        if (mp.rpg > 0)
+          while (mrow[c] >= mp.rpg) {
+            mrow[c] -= mp.rpg;
+            ++mgrp[c];
+          }
+      }
+    }
+  };
+
+  f32x4 acc[4][6], acc1[6];              // acc1: the ones-row products (bias gradient); [0..3] for sum_a, [0..5] for sum_b
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 6; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int j = 0; j < 6; ++j) acc1[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const bool sum_a = colsum != nullptr && !SWAP && wc == 0, sum_b = colsum != nullptr && SWAP && tile == 0 && wr == 0;
+  bf16x8 ones;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
+
+  const int i16 = lane & 15, fg = lane >> 4;
+  const int frow = 4 * fg + (i16 >> 2);                              // fragment row (lo); hi = +16: same row & 7, same (row>>1)&3
+  const int fcol = 8 * (i16 & 3);
+  int a_off[4], b_off[6];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) a_off[i] = frow * 256 + (((wr * 4 + i) ^ (frow & 7)) * 32) + fcol;
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    const int g = wc * 6 + j;
+    b_off[j] = A_ST + frow * 384 + (((g & ~3) | ((g & 3) ^ ((frow >> 1) & 3))) * 32) + fcol;
+  }
+
+  for (int u = 0; u < RING - 1; ++u) {
+#pragma unroll
+    for (int c = 0; c < PIECES; ++c) piece(c, u);
+    advance_load();
+  }
+  int slot = 0;
+  for (int u = 0; u < n_units; ++u) {
+    __builtin_amdgcn_s_waitcnt(vmcnt_imm((RING - 2) * PIECES));     // this unit has landed: all but the two newest
+    __builtin_amdgcn_s_barrier();                                    // ... everybody's pieces; and everybody left unit u-1's slot
+    __builtin_amdgcn_sched_barrier(0);
+    {
+      const int free_slot = slot == 0 ? RING - 1 : slot - 1;
+#pragma unroll
+      for (int c = 0; c < PIECES; ++c) piece(c, free_slot);
+      advance_load();
+    }
+    const char* base = smem + slot * UNIT;
+    bf16x8 a[4], b[6];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)LDS_PTR(base + a_off[i]));
+      const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)LDS_PTR(base + a_off[i] + 16 * 256));
+      a[i] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+    }
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)LDS_PTR(base + b_off[j]));
+      const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)LDS_PTR(base + b_off[j] + 16 * 384));
+      b[j] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 6; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    if (sum_a) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc1[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], ones, acc1[i], 0, 0, 0);
+    }
+    if (sum_b) {
+#pragma unroll
+      for (int j = 0; j < 6; ++j) acc1[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, b[j], acc1[j], 0, 0, 0);
+    }
+    __builtin_amdgcn_s_waitcnt(0xC07F);                              // lgkmcnt(0): fragment reads done before the next barrier
+    slot = slot == RING - 1 ? 0 : slot + 1;
+  }
+  __builtin_amdgcn_s_waitcnt(0x0070);                                // the padding pieces too: the ring becomes epilogue staging
+  __syncthreads();
+
+  // bias gradient: column 0 of a ones-product tile holds the sums of the 16 rows (sum_a); row 0 the sums of the 16 columns (sum_b)
+  if (sum_a && i16 == 0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n1 = n1_0 + wr * 64 + i * 16 + fg * 4 + r;
+        if (n1 < N1) atomicAdd(&colsum[n1], acc1[i][r]);
+      }
+  }
+  if (sum_b && fg == 0) {
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      const int n2 = wc * 96 + j * 16 + i16;
+      if (n2 < N2) atomicAdd(&colsum[n2], acc1[j][0]);
+    }
+  }
+  float* cs = (float*)smem;
+  for (int h = 0; h < 2; ++h) {
+    __syncthreads();
+    if (wr == h) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 6; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) cs[(i * 16 + fg * 4 + r) * T192_CS + wc * 96 + j * 16 + i16] = acc[i][j][r];
+    }
+    __syncthreads();
+    for (int idx = tid; idx < 64 * 192; idx += 256) {
+      int rl, cl;
+      if (SWAP) { cl = idx >> 6; rl = idx & 63; }            // lanes run along n1 (contiguous in the caller's transposed C)
+      else { rl = idx / 192; cl = idx % 192; }
+      const int n1 = n1_0 + h * 64 + rl;
+      if (n1 < N1 && cl < N2) {
+        float* dst = SWAP ? &C[(size_t)cl * ldc + n1] : &C[(size_t)n1 * ldc + cl];
+        atomicAdd(dst, cs[rl * T192_CS + cl]);
+      }
+    }
+  }
+}
+
 }  // namespace
 
 // ---- optional launch probe (bench.py): HIP events around every NT-GEMM launch, on the stream it is launched on.
@@ -900,10 +1117,13 @@ extern "C" int dkd_gemm_nt(const DkdGemm* gp, void* stream) {
   if (g.tap) vec_ok = vec_ok && (g.ldt % 8 == 0) && (((uintptr_t)g.tap & 15) == 0);
   const bool narrow = (g.N % 128 != 0) && (g.N % 128 <= 64);
   const int tiles_m = cdiv(g.M, BM);
-  // wide GEMMs with enough 256^2 tiles to keep 256 CUs balanced (>= 4 rounds): qkv / fc1 of the teacher
+  // wide GEMMs with enough 256 x 256 tiles for >= 4 rounds on 256 CUs: qkv / fc1 of the teacher.  (The WN = 2 instance of the
+  // kernel -- 256 x 128 tiles, two workgroups per CU -- was measured for the teacher's N = 768 GEMMs: proj 148 us, fc2 353 us
+  // against 132 / 297 us for the 128 x 128 kernel below, so they stay there.)
   const long a_last = g.amap.rpg > 0 ? (long)((g.M - 1) / g.amap.rpg) * g.amap.gstride + (g.M - 1) % g.amap.rpg + g.amap.off : g.M - 1;
   const bool fits32 = (a_last + 1) * g.lda < (1L << 31) && (long)g.N * g.ldb < (1L << 31);   // its 32-bit source offsets
-  const bool wide = vec_ok && fits32 && g.N % 256 == 0 && g.K >= 320 && (long)cdiv(g.M, 256) * (g.N / 256) >= 1024;
+  const bool ring_ok = vec_ok && fits32 && g.K >= 512;
+  const bool wide = ring_ok && g.N % 256 == 0 && (long)cdiv(g.M, 256) * (g.N / 256) >= 1024;
   ProbeScope probe(wide ? 2 : (narrow ? 1 : 0), 2.0 * g.M * g.N * g.K, as_stream(stream));
   if (wide) {
     static int n_cu = 0;
@@ -916,15 +1136,15 @@ extern "C" int dkd_gemm_nt(const DkdGemm* gp, void* stream) {
       }
       n_cu = prop.multiProcessorCount & ~7;
     }
-    const int n_tiles = cdiv(g.M, 256) * (g.N / 256);
-    const dim3 grid(n_cu);             // persistent: one workgroup per CU, tiles dealt per XCD inside the kernel
-    // bf16 C and nothing else written or read by the epilogue: 16 stores per wave per tile, counted exactly by the waits
-    const bool plain16 = !(g.epi & (DKD_EPI_RESID | DKD_EPI_DGELU | DKD_EPI_OUT_F32)) && !g.tap && !g.preact;
 #ifndef DKD_NT256_ABL
 #define DKD_NT256_ABL 0
 #endif
-    if (plain16) hipLaunchKernelGGL((gemm_nt256_kernel<DKD_NT256_ABL, 16>), grid, dim3(512), 0, as_stream(stream), g, n_tiles);
-    else hipLaunchKernelGGL((gemm_nt256_kernel<DKD_NT256_ABL, 0>), grid, dim3(512), 0, as_stream(stream), g, n_tiles);
+    const int n_tiles = cdiv(g.M, 256) * (g.N / 256);
+    const dim3 grid(n_cu);               // persistent: one workgroup per CU, tiles dealt per XCD inside the kernel
+    // bf16 C and nothing else written or read by the epilogue: 16 stores per wave per tile, counted exactly by the waits
+    const bool plain16 = !(g.epi & (DKD_EPI_RESID | DKD_EPI_DGELU | DKD_EPI_OUT_F32)) && !g.tap && !g.preact;
+    if (plain16) hipLaunchKernelGGL((gemm_nt256_kernel<DKD_NT256_ABL, 16, 4>), grid, dim3(512), 0, as_stream(stream), g, n_tiles);
+    else hipLaunchKernelGGL((gemm_nt256_kernel<DKD_NT256_ABL, 0, 4>), grid, dim3(512), 0, as_stream(stream), g, n_tiles);
     DKD_CHECK_LAUNCH("gemm_nt256");
     return DKD_OK;
   }
@@ -948,6 +1168,23 @@ extern "C" int dkd_gemm_tn(const void* A, const void* B, float* C, int32_t M, in
   const bool wide_a = !wide_b && N1 > 128 && N1 <= 192 && N2 > 192; // A is: swap roles, write transposed
   if (wide_b || wide_a) {
     const int t1 = cdiv(wide_b ? N1 : N2, 128);
+    // The LDS-DMA ring kernel needs 16-byte column granules; with fewer than 3 tile columns its blocks are too short (8 units)
+    // to amortise the 3-unit ring fill and the register-staged kernel below is faster (192 x 192: 44 vs 54 us).
+    if (N1 % 8 == 0 && N2 % 8 == 0 && t1 >= 3 && M >= 32 * 16) {
+      const int U = cdiv(M, 32);
+      int sp = cdiv(512, t1);
+      if (sp > cdiv(U, 8)) sp = cdiv(U, 8);
+      const int per = cdiv(U, sp);
+      sp = cdiv(U, per);
+      if (wide_b)
+        hipLaunchKernelGGL(gemm_tn192d_kernel<false>, dim3(t1 * sp), dim3(256), 0, as_stream(stream), (const bf16_t*)A, (const bf16_t*)B, C, M,
+                           N1, N2, lda, ldb, ldc, amap, bmap, per, a_colsum, t1);
+      else
+        hipLaunchKernelGGL(gemm_tn192d_kernel<true>, dim3(t1 * sp), dim3(256), 0, as_stream(stream), (const bf16_t*)B, (const bf16_t*)A, C, M,
+                           N2, N1, ldb, lda, ldc, bmap, amap, per, a_colsum, t1);
+      DKD_CHECK_LAUNCH("gemm_tn192d");
+      return DKD_OK;
+    }
     int sp = cdiv(512, t1);
     if (sp > cdiv(KT, 4)) sp = cdiv(KT, 4);
     if (sp < 1) sp = 1;

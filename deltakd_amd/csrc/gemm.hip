@@ -1172,7 +1172,7 @@ extern "C" int dkd_gemm_tn(const void* A, const void* B, float* C, int32_t M, in
     // to amortise the 3-unit ring fill and the register-staged kernel below is faster (192 x 192: 44 vs 54 us).
     if (N1 % 8 == 0 && N2 % 8 == 0 && t1 >= 3 && M >= 32 * 16) {
       const int U = cdiv(M, 32);
-      int sp = cdiv(512, t1);
+      int sp = cdiv(384, t1);          // 1.5 blocks per CU: fewer partial tiles to add atomically than at 2 (measured 256..768)
       if (sp > cdiv(U, 8)) sp = cdiv(U, 8);
       const int per = cdiv(U, sp);
       sp = cdiv(U, per);

@@ -170,8 +170,13 @@ def main():
     t0 = time.perf_counter()
     if a.steps > 1:
         run(a.steps - 1)
-    ops.probe_begin()                    # last timed step: HIP events around every NT-GEMM launch (roofline.achieved)
+    # Last timed step: HIP events around every NT-GEMM launch (roofline.achieved).  It runs on ONE stream: with the teacher on its
+    # side stream two kernels share the CUs and an event pair would time the sharing, not the kernel (rocprofv3's per-kernel
+    # durations of a `--no-side-stream` run are the ones to compare with: profiles/).  The step still counts in `value`.
+    side_saved, criterion.teacher_stream = criterion.teacher_stream, None
+    ops.probe_begin()
     stats = run(1)
+    criterion.teacher_stream = side_saved
     fence()
     dt = time.perf_counter() - t0
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)

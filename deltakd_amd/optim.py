@@ -115,19 +115,57 @@ class FusedAdamW(torch.optim.Optimizer):
         for sh in self._shadows:
             sh.optimizer_stepped(bf16_fresh=True)
 
-    def state_dict(self):
-        return {"step": self._step,
-                "flat": [None if f is None else {k: f[k].detach().cpu() for k in ("m", "v")} for f in self._flat],
-                "param_groups": [{k: v for k, v in g.items() if k != "params"} for g in self.param_groups]}
+    # ---- checkpoint wire format: torch.optim.AdamW's (what timm's create_optimizer builds for --opt adamw and the reference
+    # saves under checkpoint["optimizer"], /root/reference/tools/train.py:349-357), so checkpoints move both ways
+    _TORCH_GROUP_DEFAULTS = dict(amsgrad=False, maximize=False, foreach=None, capturable=False, differentiable=False, fused=None)
 
+    def state_dict(self):
+        state, groups, idx = {}, [], 0
+        for group, f in zip(self.param_groups, self._flat):
+            ids = []
+            for p in group["params"]:
+                w = self._where.get(id(p))
+                if w is not None and self._step > 0:
+                    _, s, _ = w
+                    k = p.numel()
+                    state[idx] = {"step": torch.tensor(float(self._step)),
+                                  "exp_avg": f["m"][s:s + k].view(p.shape).clone(),
+                                  "exp_avg_sq": f["v"][s:s + k].view(p.shape).clone()}
+                ids.append(idx)
+                idx += 1
+            g = dict(self._TORCH_GROUP_DEFAULTS)
+            g.update({k: v for k, v in group.items() if k != "params"})
+            g["params"] = ids
+            groups.append(g)
+        return {"state": state, "param_groups": groups}
+
+    @torch.no_grad()
     def load_state_dict(self, sd):
-        self._step = sd["step"]
-        for f, s in zip(self._flat, sd["flat"]):
-            if f is not None and s is not None:
-                f["m"].copy_(s["m"])
-                f["v"].copy_(s["v"])
-        for g, s in zip(self.param_groups, sd["param_groups"]):
-            g.update(s)
+        groups = sd["param_groups"]
+        if len(groups) != len(self.param_groups):
+            raise ValueError("loaded state dict has a different number of parameter groups")
+        steps = set()
+        for group, f, saved in zip(self.param_groups, self._flat, groups):
+            if len(saved["params"]) != len(group["params"]):
+                raise ValueError("loaded state dict contains a parameter group that doesn't match the size of optimizer's group")
+            for p, idx in zip(group["params"], saved["params"]):
+                st = sd["state"].get(idx, sd["state"].get(str(idx)))
+                w = self._where.get(id(p))
+                if st is None or w is None:
+                    continue
+                _, s, _ = w
+                k = p.numel()
+                if tuple(st["exp_avg"].shape) != tuple(p.shape):
+                    raise ValueError(f"optimizer state {idx}: shape {tuple(st['exp_avg'].shape)} does not match the parameter {tuple(p.shape)}")
+                f["m"][s:s + k].copy_(st["exp_avg"].reshape(-1))
+                f["v"][s:s + k].copy_(st["exp_avg_sq"].reshape(-1))
+                steps.add(int(float(st["step"])))
+            for key in ("lr", "betas", "eps", "weight_decay", "initial_lr"):
+                if key in saved:
+                    group[key] = tuple(saved[key]) if key == "betas" else saved[key]
+        if len(steps) > 1:
+            raise ValueError(f"FusedAdamW keeps one step count for all parameters; the checkpoint has {sorted(steps)}")
+        self._step = steps.pop() if steps else 0
 
 
 def _shadows_of(model):

@@ -29,11 +29,14 @@ class NativeScaler:
                 torch.nn.utils.clip_grad_norm_([p for p in parameters if p.grad is not None], clip_grad)
             optimizer.step()
 
+    # checkpoint["scaler"]: timm's NativeScaler saves its torch GradScaler's state; this one scales nothing, so it writes a disabled
+    # GradScaler's state (an empty dict, what torch returns for enabled=False) and accepts anything on load
     def state_dict(self):
         return {}
 
     def load_state_dict(self, state_dict):
-        pass
+        if not isinstance(state_dict, dict):
+            raise TypeError("scaler state must be a dict")
 
 
 def _one_hot(x, num_classes, on_value, off_value):

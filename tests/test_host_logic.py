@@ -175,3 +175,37 @@ def test_c_abi_library_exports_every_declared_symbol():
     # argument errors come back through the error channel, not as crashes (no kernel is launched for a bad call)
     rc = handle.dkd_gemm_nt(None, None)
     assert rc == -1 and b"null" in handle.dkd_last_error()
+
+
+def test_checkpoint_helpers_follow_the_reference_wire_format(tmp_path):
+    """tools/utils.py save_checkpoint / load_model / enable_finetune_mode (reference tools/utils.py:90-160): dict layout, best copy,
+    missing file, and the finetune path (head of another size dropped, pos_embed grid resized bicubically, prefix rows kept)."""
+    import torch
+    from deltakd_amd import vit
+    from tools.utils import enable_finetune_mode, load_model, save_checkpoint
+    torch.manual_seed(0)
+    src = vit.VisionTransformer(64, 2, 1, 10, False, 0.0, img_size=32, patch_size=8, mlp_ratio=2.0)
+    f = str(tmp_path / "ck" / "checkpoint.pth")
+    save_checkpoint({"epoch": 3, "model": {"module." + k: v for k, v in src.state_dict().items()}, "optimizer": {}, "scheduler": {},
+                     "scaler": {}}, is_best=True, filename=f)
+    assert os.path.exists(f) and os.path.exists(f.replace("pth", "best.pth"))
+    ck = torch.load(f, weights_only=True)
+    assert set(ck) == {"epoch", "model", "optimizer", "scheduler", "scaler"} and ck["epoch"] == 3
+    dst = vit.VisionTransformer(64, 2, 1, 10, False, 0.0, img_size=32, patch_size=8, mlp_ratio=2.0)
+    load_model(dst, f)                                    # strips the DDP "module." prefix
+    for (k, a), (_, b) in zip(src.state_dict().items(), dst.state_dict().items()):
+        assert torch.equal(a, b), k
+    with pytest.raises(FileNotFoundError):
+        load_model(dst, str(tmp_path / "nope.pth"))
+    # finetune: 4x4 grid -> 8x8 grid, 10 -> 7 classes
+    big = vit.VisionTransformer(64, 2, 1, 7, False, 0.0, img_size=64, patch_size=8, mlp_ratio=2.0)
+    head_before = big.head.weight.detach().clone()
+    state = {k: v.clone() for k, v in src.state_dict().items()}
+    enable_finetune_mode(big, state)
+    assert big.pos_embed.shape == (1, 1 + 64, 64)
+    assert torch.equal(big.pos_embed[:, :1], src.pos_embed[:, :1])               # cls position kept
+    grid = src.pos_embed[:, 1:].reshape(1, 4, 4, 64).permute(0, 3, 1, 2)
+    want = torch.nn.functional.interpolate(grid, size=(8, 8), mode="bicubic", align_corners=False).permute(0, 2, 3, 1).flatten(1, 2)
+    assert torch.allclose(big.pos_embed[:, 1:], want)
+    assert torch.equal(big.head.weight, head_before)                              # mismatching head left alone
+    assert torch.equal(big.blocks[1].mlp.fc1.weight, src.blocks[1].mlp.fc1.weight)

@@ -6,7 +6,8 @@ Orchestration only (out of scope as an acceleration tar
 deltakd_amd: HIP models, fused losses, FusedAdamW, RCCL data parallel.  Datasets: torchvision is absent on the MI355X
 boxes and nothing can be downloaded, so ``--data-path`` is only used when torchvision is importable; otherwise (or with
 ``--synthetic-batches N``) batches are synthetic tensors of the dataset's shape and class count, generated on the device.
-Not carried over: wandb, thop FLOP counting, checkpoint save/resume/finetune (I/O, out of scope).
+Checkpoints: the reference's wire format (tools/utils.py here, :270-286 / :349-357 there): --checkpoint with --resume or
+--finetune, one ``{save_dir}/checkpoint.pth`` (+ best copy) per epoch from rank 0.  Not carried over: wandb, thop FLOP counting.
 """
 import argparse
 import os
@@ -24,7 +25,8 @@ from deltakd_amd.losses import DistillationLoss, call_base_loss  # noqa: E402
 from deltakd_amd.models import DATASET_NUM_CLASSES, load_teacher_student_model  # noqa: E402
 from deltakd_amd.optim import create_optimizer, create_scheduler  # noqa: E402
 from deltakd_amd.shims import Mixup, ModelEma, NativeScaler  # noqa: E402
-from tools.utils import seed_everything, setup_device, setup_distributed  # noqa: E402
+from tools.utils import (enable_finetune_mode, get_model_state, remove_module_prefix, save_checkpoint, seed_everything,  # noqa: E402
+                         setup_device, setup_distributed)
 
 DISTILL_TYPES = ['none', 'soft', 'hard', 'vitkd', 'aaakd', 'vitkd_w_logit', 'aaakd_w_logit', 'lrkd', 'diffkd', 'saliency_mgd', 'curkd',
                  'wasskd', 'mgd']
@@ -106,9 +108,28 @@ def main(argv=None):
                      num_classes=classes) if mixup_active else None
     criterion = DistillationLoss(call_base_loss(args), teacher, args.distillation_type, args.alpha, args.tau,
                                  teacher_stream=torch.cuda.Stream() if device.type == "cuda" else None)
+    start_epoch = 0
+    if args.checkpoint:                  # tools/train.py:270-286 of the reference
+        if not os.path.exists(args.checkpoint):
+            raise FileNotFoundError(f"Checkpoint file not found: {args.checkpoint}")
+        checkpoint = torch.load(args.checkpoint, map_location='cpu', weights_only=True)
+        if args.resume:
+            start_epoch = checkpoint['epoch']
+            print(f"Starting from epoch: {start_epoch}")
+            optimizer.load_state_dict(checkpoint['optimizer'])
+            scheduler.load_state_dict(checkpoint['scheduler'])
+            loss_scaler.load_state_dict(checkpoint['scaler'])
+        student_state = remove_module_prefix(checkpoint['model'])
+        if args.finetune:
+            enable_finetune_mode(student, student_state)
+        else:
+            student.load_state_dict(student_state, strict=False)
+        for sh in {id(m._shadow): m._shadow for m in student.modules() if hasattr(m, "_shadow")}.values():
+            sh.optimizer_stepped(bf16_fresh=False)      # the fp32 weights changed under the bf16 copies the GEMMs read
     model = DataParallel(student, optimizer) if args.distributed else student
     model_ema = ModelEma(student, decay=args.ema_decay, optimizer=optimizer) if args.ema_decay else None
-    for epoch in range(args.epochs):
+    best_val_acc = 0.0
+    for epoch in range(start_epoch, args.epochs):
         tm = train_one_epoch(student_model=model, teacher_model=teacher, train_loader=train_loader, criterion=criterion,
                              optimizer=optimizer, loss_scaler=loss_scaler, clip_grad=args.clip_grad, mixup_fn=mixup_fn, model_ema=model_ema,
                              device=device, epoch=epoch, args=args)
@@ -116,6 +137,11 @@ def main(argv=None):
         vm = validate(model, val_loader, device, args)
         if args.rank == 0:
             print(f"Epoch {epoch} - Train: {tm} - Val: {vm}")
+            acc = float(vm.get('val_acc1', 0.0))
+            is_best, best_val_acc = acc > best_val_acc, max(acc, best_val_acc)
+            save_checkpoint({'epoch': epoch + 1, 'model': get_model_state(model), 'optimizer': optimizer.state_dict(),
+                             'scheduler': scheduler.state_dict(), 'scaler': loss_scaler.state_dict()},
+                            is_best=is_best, filename=f'{args.save_dir}/checkpoint.pth')
     if args.distributed:
         torch.distributed.destroy_process_group()
 

@@ -60,18 +60,29 @@ __global__ __launch_bounds__(64 * FWD_WAVES, 2) void attn_fwd_kernel(const bf16_
   const bf16_t* base = qkv + (size_t)b * N * ld + h * 64;
   char* Ks = smem;
   char* Vs = smem + NKT * 16 * KV_LD;
+  // Q fragments of all of this wave's query tiles are requested BEFORE K/V are staged: loaded inside the tile loop, each tile began
+  // with a strided global load whose full latency was exposed (two waves per SIMD do not hide ~2 us), 3-4 times per wave.
+  constexpr int MAXQ = (NKT + FWD_WAVES - 1) / FWD_WAVES;
+  const int nqt = (N + 15) >> 4;
+  bf16x8 qall[MAXQ][2];
+#pragma unroll
+  for (int it = 0; it < MAXQ; ++it) {
+    const int q = (w + it * FWD_WAVES) * 16 + i16;
+    const int qc = q < N ? q : N - 1;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) qall[it][ks] = *(const bf16x8*)(base + (size_t)qc * ld + ks * 32 + 8 * fg);
+  }
   stage_rows<64 * FWD_WAVES>(Ks, base + D, ld, N, NKT * 16, tid);
   stage_rows<64 * FWD_WAVES>(Vs, base + 2 * D, ld, N, NKT * 16, tid);
   __syncthreads();
 
   const float c = 0.125f * LOG2E;
-  const int nqt = (N + 15) >> 4;
-  for (int qt = w; qt < nqt; qt += FWD_WAVES) {
-    const int q = qt * 16 + i16;
-    const int qc = q < N ? q : N - 1;
-    bf16x8 qf[2];
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) qf[ks] = *(const bf16x8*)(base + (size_t)qc * ld + ks * 32 + 8 * fg);
+  for (int it = 0; it < MAXQ; ++it) {
+    const int qt = w + it * FWD_WAVES;
+    if (qt >= nqt) break;
+    const int q = qt * 16 + i16;
+    const bf16x8 (&qf)[2] = qall[it];
     // Softmax VALU budget (the kernel is VALU-bound, not MFMA-bound): per score one max, one fma (scale folded into the exp2
     // argument), one exp2, one add; masking touches only the key tiles that straddle or exceed N.
     f32x4 s[NKT];
@@ -129,6 +140,161 @@ __global__ __launch_bounds__(64 * FWD_WAVES, 2) void attn_fwd_kernel(const bf16_
       for (int dt = 0; dt < 4; ++dt) store4bf(op + dt * 16, o[dt], inv);
       if (lse && fg == 0) lse[((size_t)b * H + h) * N + q] = mxc * LN2 + __logf(sum);
     }
+  }
+}
+
+// ---- forward, persistent: one 8-wave workgroup per CU walks heads; K/V of head k+1 stream into the second LDS buffer by LDS-DMA
+// while head k is computed.  The kernel above spends 33 us staging (HBM-bound: 155 MB of K/V) and 64 us computing per teacher
+// layer and the two do not overlap -- both workgroups of a CU stage at the same time, then both compute (127 us; the layer's HBM
+// floor is 311 MB / 5 TB/s = 62 us).
+//  * LDS rows are unpadded (a DMA writes 1 KiB linearly): K 16-B slots are XOR-swizzled by (row>>1)&7 (ds_read_b128 row reads),
+//    V 32-B granules by (row>>1)&3 (ds_read_b64_tr_b16 reads), both on the per-lane DMA source address and the fragment reads.
+//    Rows past N are sourced from row N-1 (finite; their scores are masked / their probabilities are 0).
+//  * ordering: the Q fragments of head k+1 are loaded (ordinary global loads) right AFTER the DMA of head k+1 is issued; the
+//    vector-memory counter is in order, so the wait the compiler places before their first use -- forced to sit before the
+//    barrier that opens head k+1 -- also covers the DMA, without draining the output stores issued after them.
+template <int NKT>
+__global__ __launch_bounds__(512, 1) void attn_fwd_ring_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
+                                                                float* __restrict__ lse, int N, int H, int n_heads) {
+  constexpr int NW = 8, ROWS = NKT * 16, MAT = ROWS * 128, BUF = 2 * MAT, NPIECE = 2 * (ROWS / 8);
+  constexpr int MAXQ = (NKT + NW - 1) / NW;
+  extern __shared__ __attribute__((aligned(16))) char smem[];       // [2][K | V]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i16 = lane & 15, fg = lane >> 4;
+  const int D = H * 64, ld = 3 * D;
+  const int nqt = (N + 15) >> 4;
+  const float c = 0.125f * LOG2E;
+  const int my_heads = ((int)blockIdx.x < n_heads) ? (n_heads - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
+  if (my_heads == 0) return;
+
+  auto head_base = [&](int k) {
+    const int hd = blockIdx.x + k * gridDim.x;
+    return qkv + (size_t)(hd / H) * N * ld + (hd % H) * 64;
+  };
+  auto issue_dma = [&](int k) {
+    const bf16_t* base = head_base(k);
+    const uint32_t dst0 = (uint32_t)(uintptr_t)LDS_PTR(smem) + (k & 1) * BUF;
+    for (int p = w; p < NPIECE; p += NW) {
+      const bool isv = p >= ROWS / 8;
+      const int row = (isv ? p - ROWS / 8 : p) * 8 + (lane >> 3);
+      const int ph = lane & 7;
+      const int col = isv ? (((ph >> 1) ^ ((row >> 1) & 3)) * 2 + (ph & 1)) * 8 : (ph ^ ((row >> 1) & 7)) * 8;
+      const bf16_t* src = base + (isv ? 2 * D : D) + (size_t)(row < N ? row : N - 1) * ld + col;
+      const uint32_t dst = dst0 + p * 1024;
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+      asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(dst), "v"(src) : "memory", "m0");
+#pragma clang diagnostic pop
+    }
+  };
+  auto load_q = [&](bf16x8 (&qf)[MAXQ][2], int k) {
+    const bf16_t* base = head_base(k);
+#pragma unroll
+    for (int it = 0; it < MAXQ; ++it) {
+      const int q = (w + it * NW) * 16 + i16;
+      const int qc = q < N ? q : N - 1;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) qf[it][ks] = *(const bf16x8*)(base + (size_t)qc * ld + ks * 32 + 8 * fg);
+    }
+  };
+
+  // fragment addresses inside a buffer: the swizzle keys depend on the lane only (row = 16 kt + i16 resp. 32 kp + 4 fg + i16/4),
+  // so every read is one of these bases plus an immediate
+  int k_off[2], v_off[4];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) k_off[ks] = i16 * 128 + (((ks * 4 + fg) ^ ((i16 >> 1) & 7)) * 16);
+  {
+    const int row = 4 * fg + (i16 >> 2);
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) v_off[dt] = row * 128 + ((dt ^ ((row >> 1) & 3)) * 32) + 8 * (i16 & 3);
+  }
+  bf16x8 qcur[MAXQ][2], qnext[MAXQ][2];
+  issue_dma(0);
+  load_q(qcur, 0);
+  for (int k = 0; k < my_heads; ++k) {
+    // the Q fragments of this head are in registers => (in-order counter) its K/V pieces issued before them have landed
+#pragma unroll
+    for (int it = 0; it < MAXQ; ++it)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) asm volatile("" ::"v"(qcur[it][ks]));
+    __syncthreads();                     // everybody's pieces; and everybody is done with the other buffer (head k-1)
+    if (k + 1 < my_heads) {
+      issue_dma(k + 1);
+      load_q(qnext, k + 1);
+    }
+    const char* Ks = smem + (k & 1) * BUF;
+    const char* Vs = Ks + MAT;
+    const int hd = blockIdx.x + k * gridDim.x;
+    const int b = hd / H, h = hd % H;
+#pragma unroll
+    for (int it = 0; it < MAXQ; ++it) {
+      const int qt = w + it * NW;
+      if (qt < nqt) {
+        const int q = qt * 16 + i16;
+        f32x4 s[NKT];
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt) {
+          s[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks) {
+            const bf16x8 kf = *(const bf16x8*)(Ks + k_off[ks] + kt * 2048);
+            s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qcur[it][ks], s[kt], 0, 0, 0);
+          }
+        }
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt) {
+          if (kt * 16 + 16 > N) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (kt * 16 + 4 * fg + r >= N) s[kt][r] = -INFINITY;
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[kt][r]);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float mxc = mx * c;
+        float sum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float pr = __builtin_amdgcn_exp2f(fmaf(s[kt][r], c, -mxc));
+            s[kt][r] = pr;
+            sum += pr;
+          }
+        sum += __shfl_xor(sum, 16, 64);
+        sum += __shfl_xor(sum, 32, 64);
+        f32x4 o[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kp = 0; kp < NKT / 2; ++kp) {
+          const bf16x8 pf = pack8(s[2 * kp], s[2 * kp + 1]);
+#pragma unroll
+          for (int dt = 0; dt < 4; ++dt) {
+            const char* pv = Vs + v_off[dt] + kp * 4096;
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)LDS_PTR(pv));
+            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)LDS_PTR(pv + 16 * 128));
+            const bf16x8 vf = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+            o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, o[dt], 0, 0, 0);
+          }
+        }
+        if (q < N) {
+          const float inv = 1.f / sum;
+          bf16_t* op = out + ((size_t)b * N + q) * D + h * 64 + 4 * fg;
+#pragma unroll
+          for (int dt = 0; dt < 4; ++dt) store4bf(op + dt * 16, o[dt], inv);
+          if (lse && fg == 0) lse[((size_t)b * H + h) * N + q] = mxc * LN2 + __logf(sum);
+        }
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < MAXQ; ++it)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) qcur[it][ks] = qnext[it][ks];
   }
 }
 
@@ -342,6 +508,26 @@ extern "C" int dkd_attn_fwd(const void* qkv, void* out, float* lse, int32_t B, i
   DKD_CHECK_ARG(B > 0 && H > 0 && N > 0 && N <= 256, "attn_fwd: need 0 < N <= 256 (got N=%d B=%d H=%d)", N, B, H);
   const int nt = pick_tiles(N);
   const int smem = 2 * nt * 16 * KV_LD;
+  static int n_cu = 0;
+  if (!n_cu) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) {
+      dkd_set_error("attn_fwd: cannot query the device");
+      return DKD_ERR_HIP;
+    }
+    n_cu = prop.multiProcessorCount;
+  }
+  if (nt >= 8 && B * H >= 2 * n_cu) {    // enough heads per CU for the double-buffered persistent kernel to pay
+    const int smem_ring = 2 * 2 * nt * 16 * 128;
+    DISPATCH_NT(nt, {
+      if (int rc = set_smem(attn_fwd_ring_kernel<T>, smem_ring)) return rc;
+      hipLaunchKernelGGL(attn_fwd_ring_kernel<T>, dim3(n_cu), dim3(512), smem_ring, as_stream(stream), (const bf16_t*)qkv, (bf16_t*)out, lse, N,
+                         H, B * H);
+    });
+    DKD_CHECK_LAUNCH("attn_fwd_ring");
+    return DKD_OK;
+  }
   DISPATCH_NT(nt, {
     if (int rc = set_smem(attn_fwd_kernel<T>, smem)) return rc;
     hipLaunchKernelGGL(attn_fwd_kernel<T>, dim3(B * H), dim3(64 * FWD_WAVES), smem, as_stream(stream), (const bf16_t*)qkv, (bf16_t*)out, lse, N, H);

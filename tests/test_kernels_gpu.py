@@ -165,6 +165,17 @@ def test_attn_fwd_bwd(ops, B, N, H):
         close(d[:, :, i], g[:, :, i], 3e-2, f"d{nm}")
 
 
+@pytest.mark.parametrize("B,N,H", [(48, 198, 12), (200, 197, 3), (70, 130, 8), (40, 256, 16)])
+def test_attn_fwd_persistent_kernel(ops, B, N, H):
+    """>= 2 heads per CU route to the double-buffered persistent forward (LDS-DMA K/V ring, swizzled unpadded rows); odd head
+    counts per workgroup, N on and off a 16-row boundary, the 14- and 16-tile instantiations."""
+    qkv = rnd(B * N, 3 * H * 64, scale=1.5, seed=22).to(BF16)
+    out, lse = ops.attn_fwd(qkv, B, N, H)
+    ref, ref_lse = ref_attention(qkv, B, N, H)
+    close(out, ref, 1.5e-2, "attn out (ring)")
+    close(lse.view(B, H, N), ref_lse, 1e-3, "lse (ring)")
+
+
 @pytest.mark.parametrize("M,D", [(7, 64), (300, 192), (129, 768), (50, 1024)])
 def test_layernorm(ops, M, D):
     x = rnd(M, D, scale=2.0, seed=30) + 0.5

@@ -142,7 +142,9 @@ __device__ __forceinline__ void epi_finish(const DkdGemm& g, const int vec_ok, f
 
 // ---- epilogue shared by the 128-row NT kernels: ONE pass through LDS (f32 [128][BN], unpadded: the accumulator-layout
 // ds_write_b32 is only 2-way per 32-lane group = free, the row reads are contiguous), then 16-B coalesced fused stores.
-template <int BN, int NJ>
+// FAST 3: C(f32) = resid + acc + bias with identity row maps, no row scale (the teacher's proj / fc2; bf16 tap optional) -- compiled
+// without the generic path's per-vector flag tests and row-map arithmetic.  0: generic.
+template <int BN, int NJ, int FAST>
 __device__ __forceinline__ void nt_epilogue(const DkdGemm& g, const int vec_ok, char* smem, f32x4 (&acc)[4][NJ], const int m0,
                                             const int n0, const int tid, const int wr, const int wc) {
   const int lane = tid & 63, frow = lane & 15, fg = lane >> 4;
@@ -160,6 +162,39 @@ __device__ __forceinline__ void nt_epilogue(const DkdGemm& g, const int vec_ok, 
   const int col8 = (tid % TPR) * 8, r0 = tid / TPR;
   const int n = n0 + col8;
   if (n >= g.N) return;
+  if (FAST == 3) {
+    constexpr int SW = 64 / RPP;
+    const f32x4 b0 = *(const f32x4*)&g.bias[n], b1 = *(const f32x4*)&g.bias[n + 4];
+    const bool tap = g.tap != nullptr;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      f32x4 r0v[SW], r1v[SW];
+#pragma unroll
+      for (int s = 0; s < SW; ++s) {
+        const int m = m0 + half * 64 + r0 + RPP * s;
+        if (m < g.M) {
+          const float* rp = &g.resid[(size_t)m * g.ldr + n];
+          r0v[s] = *(const f32x4*)rp;
+          r1v[s] = *(const f32x4*)(rp + 4);
+        }
+      }
+#pragma unroll
+      for (int s = 0; s < SW; ++s) {
+        const int rl = half * 64 + r0 + RPP * s;
+        const int m = m0 + rl;
+        if (m < g.M) {
+          const f32x4 lo = *(const f32x4*)&cs[rl * BN + col8] + b0, hi = *(const f32x4*)&cs[rl * BN + col8 + 4] + b1;
+          if (tap)
+            *(uint4*)&((bf16_t*)g.tap)[(size_t)m * g.ldt + n] = uint4{pack2bf(lo[0], lo[1]), pack2bf(lo[2], lo[3]), pack2bf(hi[0], hi[1]),
+                                                                       pack2bf(hi[2], hi[3])};
+          float* cp = (float*)g.C + (size_t)m * g.ldc + n;
+          *(f32x4*)cp = r0v[s] + lo;
+          *(f32x4*)(cp + 4) = r1v[s] + hi;
+        }
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int half = 0; half < 2; ++half) {
     constexpr int SW = 64 / RPP;         // sweeps per 64-row half
@@ -181,7 +216,7 @@ __device__ __forceinline__ void nt_epilogue(const DkdGemm& g, const int vec_ok, 
   }
 }
 
-template <int BN>
+template <int BN, int FAST = 0>
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const DkdGemm g, const int vec_ok) {
   constexpr int NJ = BN / 32;             // 16-col MFMA tiles per wave along N
   constexpr int A_BYTES = BM * 128;       // 16 KiB
@@ -263,7 +298,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const DkdGemm g, const 
     }
   }
 
-  nt_epilogue<BN, NJ>(g, vec_ok, smem, acc, m0, n0, tid, wr, wc);
+  nt_epilogue<BN, NJ, FAST>(g, vec_ok, smem, acc, m0, n0, tid, wr, wc);
 }
 
 // ---- 256 x 256 tile, 8 waves (2 x 4, 128 x 64 per wave), PERSISTENT, one workgroup per CU: for the wide teacher GEMMs.
@@ -296,7 +331,10 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const DkdGemm g, const 
 //        tiles leave 256 CUs with 2.3 rounds of work; it moves 25 % less operand data through the LDS-DMA path than the
 //        128 x 128 kernel, and the second workgroup computes while the first one's f32 residual epilogue drains.
 constexpr uint32_t vmcnt_imm(int n) { return (uint32_t)((n & 15) | ((n >> 4) << 14) | 0x0F70); }   // s_waitcnt vmcnt(n) only
-template <int ABL, int EOPS, int WN>
+// FAST: 0 = the generic fused epilogue (runtime flags, row maps); 1 = C(bf16) = acc + bias; 2 = C(bf16) = gelu(acc + bias), both with
+// identity row maps -- the two epilogues the teacher's qkv / fc1 use, compiled without the per-vector flag tests, row-map
+// divisions and spilled-SGPR reads of the generic path (they, not the GELU arithmetic, were most of the epilogue's VALU time).
+template <int ABL, int EOPS, int WN, int FAST>
 __global__ __launch_bounds__(128 * WN, WN == 4 ? 1 : 2) void gemm_nt256_kernel(const DkdGemm g, const int n_tiles) {
   constexpr int BN = 64 * WN, NW = 2 * WN;          // tile columns, waves
   constexpr int WHALF = 16384, UNIT = WHALF + BN * 64, RING = WN == 4 ? 5 : 3;
@@ -482,14 +520,20 @@ __global__ __launch_bounds__(128 * WN, WN == 4 ? 1 : 2) void gemm_nt256_kernel(c
         if (m < g.M) {
           EpiIn in[2];
 #pragma unroll
-          for (int jp = 0; jp < 2; ++jp) in[jp] = epi_prefetch(g, 1, m, nb + jp * 32);
+          for (int jp = 0; jp < 2; ++jp)
+            if (!FAST) in[jp] = epi_prefetch(g, 1, m, nb + jp * 32);
 #pragma unroll
           for (int jp = 0; jp < 2; ++jp) {
             const f32x4 lo = acc[i][2 * jp], hi = acc[i][2 * jp + 1];
-            if (EOPS == 16 && !(g.epi & ~DKD_EPI_BIAS)) {
-              // bias-only bf16 output (qkv): streaming store -- the 230 MB output is not re-read from L2
+            if (FAST) {
+              // streaming store: the 230-310 MB output is not re-read from L2 by this kernel
               typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-              const uint4 pk = pack8(f32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]} + bias8[jp]);
+              f32x8 v = f32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]} + bias8[jp];
+              if (FAST == 2) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = gelu_erf(v[e]);
+              }
+              const uint4 pk = pack8(v);
               __builtin_nontemporal_store(u32x4{pk.x, pk.y, pk.z, pk.w}, (u32x4*)((bf16_t*)g.C + (size_t)m * g.ldc + nb + jp * 32));
             } else
             epi_finish(g, 1, f32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]} + bias8[jp], in[jp], m, nb + jp * 32, true);
@@ -1143,15 +1187,22 @@ extern "C" int dkd_gemm_nt(const DkdGemm* gp, void* stream) {
     const dim3 grid(n_cu);               // persistent: one workgroup per CU, tiles dealt per XCD inside the kernel
     // bf16 C and nothing else written or read by the epilogue: 16 stores per wave per tile, counted exactly by the waits
     const bool plain16 = !(g.epi & (DKD_EPI_RESID | DKD_EPI_DGELU | DKD_EPI_OUT_F32)) && !g.tap && !g.preact;
-    if (plain16) hipLaunchKernelGGL((gemm_nt256_kernel<DKD_NT256_ABL, 16, 4>), grid, dim3(512), 0, as_stream(stream), g, n_tiles);
-    else hipLaunchKernelGGL((gemm_nt256_kernel<DKD_NT256_ABL, 0, 4>), grid, dim3(512), 0, as_stream(stream), g, n_tiles);
+    const bool ident = g.cmap.rpg == 0 && !g.rowscale && (g.epi & DKD_EPI_BIAS);
+    const int fast = !(plain16 && ident) ? 0 : (g.epi == DKD_EPI_BIAS ? 1 : (g.epi == (DKD_EPI_BIAS | DKD_EPI_GELU) ? 2 : 0));
+    if (fast == 1) hipLaunchKernelGGL((gemm_nt256_kernel<DKD_NT256_ABL, 16, 4, 1>), grid, dim3(512), 0, as_stream(stream), g, n_tiles);
+    else if (fast == 2) hipLaunchKernelGGL((gemm_nt256_kernel<DKD_NT256_ABL, 16, 4, 2>), grid, dim3(512), 0, as_stream(stream), g, n_tiles);
+    else if (plain16) hipLaunchKernelGGL((gemm_nt256_kernel<DKD_NT256_ABL, 16, 4, 0>), grid, dim3(512), 0, as_stream(stream), g, n_tiles);
+    else hipLaunchKernelGGL((gemm_nt256_kernel<DKD_NT256_ABL, 0, 4, 0>), grid, dim3(512), 0, as_stream(stream), g, n_tiles);
     DKD_CHECK_LAUNCH("gemm_nt256");
     return DKD_OK;
   }
   if (narrow) {
-    hipLaunchKernelGGL(gemm_nt_kernel<64>, dim3(tiles_m * cdiv(g.N, 64)), dim3(256), 0, as_stream(stream), g, vec_ok);
+    hipLaunchKernelGGL((gemm_nt_kernel<64, 0>), dim3(tiles_m * cdiv(g.N, 64)), dim3(256), 0, as_stream(stream), g, vec_ok);
   } else {
-    hipLaunchKernelGGL(gemm_nt_kernel<128>, dim3(tiles_m * cdiv(g.N, 128)), dim3(256), 0, as_stream(stream), g, vec_ok);
+    const bool fast3 = vec_ok && g.N % 128 == 0 && g.epi == (DKD_EPI_BIAS | DKD_EPI_RESID | DKD_EPI_OUT_F32) && !g.rowscale &&
+                       g.cmap.rpg == 0 && g.rmap.rpg == 0 && !g.preact && !(g.tap && (g.epi & DKD_EPI_TAP_F32));
+    if (fast3) hipLaunchKernelGGL((gemm_nt_kernel<128, 3>), dim3(tiles_m * cdiv(g.N, 128)), dim3(256), 0, as_stream(stream), g, vec_ok);
+    else hipLaunchKernelGGL((gemm_nt_kernel<128, 0>), dim3(tiles_m * cdiv(g.N, 128)), dim3(256), 0, as_stream(stream), g, vec_ok);
   }
   DKD_CHECK_LAUNCH("gemm_nt");
   return DKD_OK;

@@ -59,21 +59,27 @@ extern "C" int dkd_block_bwd(const DkdBlock* bp, const DkdBlockGrads* gp, void* 
   const int M = b.B * b.N, D = b.D, Hd = b.hidden;
   // ---- MLP branch
   TRY(dkd_scale_cast_bf16(r.g, D, ID, b.s2, b.N, r.gtap, 0, D, r.dF, D, M, D, st));
-  TRY(dkd_gemm_tn(r.dF, b.h, r.d_fc2_w, M, D, Hd, D, Hd, Hd, ID, ID, r.d_fc2_b, st));
   DkdGemm g = mk(r.dF, b.fc2_wt, r.dH, M, Hd, D);
   g.epi = DKD_EPI_DGELU; g.preact = b.pre; g.ldp = Hd;
   TRY(dkd_gemm_nt(&g, st));
-  TRY(dkd_gemm_tn(r.dH, b.y2, r.d_fc1_w, M, Hd, D, Hd, D, D, ID, ID, r.d_fc1_b, st));
+  {                                     // both MLP weight gradients in one launch (dF is not overwritten before the attention branch)
+    const DkdTnProblem w[2] = {{r.dF, b.h, r.d_fc2_w, r.d_fc2_b, M, D, Hd, D, Hd, Hd, ID, ID},
+                               {r.dH, b.y2, r.d_fc1_w, r.d_fc1_b, M, Hd, D, Hd, D, D, ID, ID}};
+    TRY(dkd_gemm_tn_group(w, 2, st));
+  }
   g = mk(r.dH, b.fc1_wt, r.dT, M, D, Hd);
   TRY(dkd_gemm_nt(&g, st));
   TRY(dkd_layernorm_bwd(r.dT, 0, b.x1, D, ID, b.ln2_w, b.mean2, b.rstd2, r.g, D, ID, 1, r.d_ln2_w, r.d_ln2_b, M, D, st));
   // ---- attention branch
   TRY(dkd_scale_cast_bf16(r.g, D, ID, b.s1, b.N, nullptr, 1, 0, r.dF, D, M, D, st));
-  TRY(dkd_gemm_tn(r.dF, b.o, r.d_proj_w, M, D, D, D, D, D, ID, ID, r.d_proj_b, st));
   g = mk(r.dF, b.proj_wt, r.dT, M, D, D);
   TRY(dkd_gemm_nt(&g, st));
   TRY(dkd_attn_bwd(b.qkv, b.o, r.dT, b.lse, r.dqkv, b.B, b.N, b.H, st));
-  TRY(dkd_gemm_tn(r.dqkv, b.y1, r.d_qkv_w, M, 3 * D, D, 3 * D, D, D, ID, ID, r.d_qkv_b, st));
+  {                                     // proj and qkv weight gradients in one launch
+    const DkdTnProblem w[2] = {{r.dF, b.o, r.d_proj_w, r.d_proj_b, M, D, D, D, D, D, ID, ID},
+                               {r.dqkv, b.y1, r.d_qkv_w, r.d_qkv_b, M, 3 * D, D, 3 * D, D, D, ID, ID}};
+    TRY(dkd_gemm_tn_group(w, 2, st));
+  }
   g = mk(r.dqkv, b.qkv_wt, r.dT, M, D, 3 * D);
   TRY(dkd_gemm_nt(&g, st));
   TRY(dkd_layernorm_bwd(r.dT, 0, b.x, D, ID, b.ln1_w, b.mean1, b.rstd1, r.g, D, ID, 1, r.d_ln1_w, r.d_ln1_b, M, D, st));

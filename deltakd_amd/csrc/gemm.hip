@@ -874,21 +874,34 @@ __global__ __launch_bounds__(256, 2) void gemm_tn192_kernel(const bf16_t* __rest
 //  * the fused bias gradient (column sums of dY) is one more MFMA per row tile against a fragment of ones.
 __device__ uint4 dkd_zero16 = {0u, 0u, 0u, 0u};
 
-template <bool SWAP>
-__global__ __launch_bounds__(256, 2) void gemm_tn192d_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, float* C, int M,
-                                                             int N1, int N2, int lda, int ldb, int ldc, DkdRowMap amap, DkdRowMap bmap,
-                                                             int units_per_split, float* __restrict__ colsum, int tiles1) {
-  constexpr int A_ST = 32 * 256, UNIT = A_ST + 32 * 384, RING = 4, PIECES = 5;   // per wave: 2 pieces of A, 3 of B
-  constexpr int SMEM = RING * UNIT;                                              // 80 KiB; the epilogue reuses 49 KiB of it
-  static_assert(SMEM >= 64 * T192_CS * 4, "epilogue staging must fit");
-  __shared__ __attribute__((aligned(16))) char smem[SMEM];
+constexpr int TND_A_ST = 32 * 256, TND_UNIT = TND_A_ST + 32 * 384, TND_RING = 4;
+constexpr int TND_SMEM = TND_RING * TND_UNIT;                                    // 80 KiB; the epilogue reuses 49 KiB of it
+static_assert(TND_SMEM >= 64 * T192_CS * 4, "epilogue staging must fit");
+
+// One problem of the kernel, in kernel-operand order (the host has already swapped the operands when the wide one is A).
+struct TnProb {
+  const bf16_t* A;
+  const bf16_t* B;
+  float* C;
+  float* colsum;
+  int M, N1, N2, lda, ldb, ldc;
+  DkdRowMap amap, bmap;
+  int units_per_split, tiles1, swap, n_blocks;     // n_blocks: tiles1 * splits rounded up to a multiple of 8
+};
+
+// `bid` / `nblk`: this block's index inside its problem and the problem's block count (both in launch order, so bid % 8 is the XCD)
+__device__ __forceinline__ void tn192d_body(char* smem, const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, float* C, int M,
+                                            int N1, int N2, int lda, int ldb, int ldc, const DkdRowMap& amap, const DkdRowMap& bmap,
+                                            int units_per_split, float* __restrict__ colsum, int tiles1, const bool SWAP, int bid,
+                                            int nblk) {
+  constexpr int A_ST = TND_A_ST, UNIT = TND_UNIT, RING = TND_RING, PIECES = 5;   // per wave: 2 pieces of A, 3 of B
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = w >> 1, wc = w & 1;
   // 1-D grid, XCD-aware: each XCD gets a contiguous run of (split, tile) ids with the tiles of a split adjacent, so the blocks
   // that stream the same rows of the 192-wide operand run on the same XCD at the same time and share them through its L2
   // (dealt round-robin, every XCD fetched those rows again: twice the HBM/fabric traffic for a 768 x 192 gradient)
-  const int L = xcd_remap(blockIdx.x, gridDim.x);
+  const int L = xcd_remap(bid, nblk);
   const int tile = L % tiles1, split = L / tiles1;
   const int n1_0 = tile * 128;
   const int U_all = (M + 31) / 32;
@@ -1077,6 +1090,34 @@ __global__ __launch_bounds__(256, 2) void gemm_tn192d_kernel(const bf16_t* __res
   }
 }
 
+template <bool SWAP>
+__global__ __launch_bounds__(256, 2) void gemm_tn192d_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, float* C, int M,
+                                                             int N1, int N2, int lda, int ldb, int ldc, DkdRowMap amap, DkdRowMap bmap,
+                                                             int units_per_split, float* __restrict__ colsum, int tiles1) {
+  __shared__ __attribute__((aligned(16))) char smem[TND_SMEM];
+  tn192d_body(smem, A, B, C, M, N1, N2, lda, ldb, ldc, amap, bmap, units_per_split, colsum, tiles1, SWAP, blockIdx.x, gridDim.x);
+}
+
+// Up to four independent weight gradients in ONE launch (the two of an MLP, the two of an attention branch): each alone is ~1.5
+// blocks per CU that all start and end together, so its ring fill and its atomic epilogue overlap nothing; side by side the blocks
+// of one problem fill in while another's drain.  Block ranges are padded to multiples of 8 so blockIdx % 8 stays the XCD.
+struct TnGroup {
+  TnProb p[4];
+  int n;
+};
+__global__ __launch_bounds__(256, 2) void gemm_tn192g_kernel(const TnGroup grp) {
+  __shared__ __attribute__((aligned(16))) char smem[TND_SMEM];
+  int bid = blockIdx.x, k = 0;
+  while (k + 1 < grp.n && bid >= grp.p[k].n_blocks) {
+    bid -= grp.p[k].n_blocks;
+    ++k;
+  }
+  const TnProb& q = grp.p[k];
+  if (bid >= q.n_blocks) return;
+  tn192d_body(smem, q.A, q.B, q.C, q.M, q.N1, q.N2, q.lda, q.ldb, q.ldc, q.amap, q.bmap, q.units_per_split, q.colsum, q.tiles1,
+              q.swap != 0, bid, q.n_blocks);
+}
+
 }  // namespace
 
 // ---- optional launch probe (bench.py): HIP events around every NT-GEMM launch, on the stream it is launched on.
@@ -1208,6 +1249,65 @@ extern "C" int dkd_gemm_nt(const DkdGemm* gp, void* stream) {
   return DKD_OK;
 }
 
+namespace {
+// kernel-order description of one weight gradient for the LDS-DMA ring kernel, or false when it must take the other kernels
+bool tn192d_plan(const DkdTnProblem& q, TnProb* out, int min_tiles) {
+  const bool wide_b = q.N2 > 128 && q.N2 <= 192;
+  const bool wide_a = !wide_b && q.N1 > 128 && q.N1 <= 192 && q.N2 > 192;
+  if (!(wide_b || wide_a) || q.N1 % 8 || q.N2 % 8 || q.M < 32 * 16) return false;
+  if ((q.lda % 8) || (q.ldb % 8) || ((uintptr_t)q.A & 15) || ((uintptr_t)q.B & 15)) return false;
+  const int t1 = cdiv(wide_b ? q.N1 : q.N2, 128);
+  if (t1 < min_tiles) return false;
+  const int U = cdiv(q.M, 32);
+  int sp = cdiv(384, t1);              // 1.5 blocks per CU: fewer partial tiles to add atomically than at 2 (measured 256..768)
+  if (sp > cdiv(U, 8)) sp = cdiv(U, 8);
+  const int per = cdiv(U, sp);
+  sp = cdiv(U, per);
+  TnProb p;
+  p.A = (const bf16_t*)(wide_b ? q.A : q.B);
+  p.B = (const bf16_t*)(wide_b ? q.B : q.A);
+  p.C = q.C;
+  p.colsum = q.a_colsum;
+  p.M = q.M;
+  p.N1 = wide_b ? q.N1 : q.N2;
+  p.N2 = wide_b ? q.N2 : q.N1;
+  p.lda = wide_b ? q.lda : q.ldb;
+  p.ldb = wide_b ? q.ldb : q.lda;
+  p.ldc = q.ldc;
+  p.amap = wide_b ? q.amap : q.bmap;
+  p.bmap = wide_b ? q.bmap : q.amap;
+  p.units_per_split = per;
+  p.tiles1 = t1;
+  p.swap = wide_b ? 0 : 1;
+  p.n_blocks = (t1 * sp + 7) & ~7;
+  *out = p;
+  return true;
+}
+}  // namespace
+
+extern "C" int dkd_gemm_tn_group(const DkdTnProblem* probs, int32_t n, void* stream) {
+  DKD_CHECK_ARG(probs && n > 0 && n <= 4, "gemm_tn_group: need 1..4 problems (n=%d)", n);
+  TnGroup grp;
+  grp.n = 0;
+  int total = 0;
+  for (int i = 0; i < n; ++i) {
+    const DkdTnProblem& q = probs[i];
+    DKD_CHECK_ARG(q.A && q.B && q.C && q.M > 0 && q.N1 > 0 && q.N2 > 0, "gemm_tn_group: bad problem %d", i);
+    if (tn192d_plan(q, &grp.p[grp.n], 1)) {
+      total += grp.p[grp.n].n_blocks;
+      ++grp.n;
+    } else {                            // shapes the ring kernel does not take: launched on their own
+      int rc = dkd_gemm_tn(q.A, q.B, q.C, q.M, q.N1, q.N2, q.lda, q.ldb, q.ldc, q.amap, q.bmap, q.a_colsum, stream);
+      if (rc != DKD_OK) return rc;
+    }
+  }
+  if (grp.n > 0) {
+    hipLaunchKernelGGL(gemm_tn192g_kernel, dim3(total), dim3(256), 0, as_stream(stream), grp);
+    DKD_CHECK_LAUNCH("gemm_tn_group");
+  }
+  return DKD_OK;
+}
+
 extern "C" int dkd_gemm_tn(const void* A, const void* B, float* C, int32_t M, int32_t N1, int32_t N2, int32_t lda, int32_t ldb,
                            int32_t ldc, DkdRowMap amap, DkdRowMap bmap, float* a_colsum, void* stream) {
   DKD_CHECK_ARG(A && B && C, "gemm_tn: null operand");
@@ -1220,19 +1320,18 @@ extern "C" int dkd_gemm_tn(const void* A, const void* B, float* C, int32_t M, in
   if (wide_b || wide_a) {
     const int t1 = cdiv(wide_b ? N1 : N2, 128);
     // The LDS-DMA ring kernel needs 16-byte column granules; with fewer than 3 tile columns its blocks are too short (8 units)
-    // to amortise the 3-unit ring fill and the register-staged kernel below is faster (192 x 192: 44 vs 54 us).
-    if (N1 % 8 == 0 && N2 % 8 == 0 && t1 >= 3 && M >= 32 * 16) {
-      const int U = cdiv(M, 32);
-      int sp = cdiv(384, t1);          // 1.5 blocks per CU: fewer partial tiles to add atomically than at 2 (measured 256..768)
-      if (sp > cdiv(U, 8)) sp = cdiv(U, 8);
-      const int per = cdiv(U, sp);
-      sp = cdiv(U, per);
-      if (wide_b)
-        hipLaunchKernelGGL(gemm_tn192d_kernel<false>, dim3(t1 * sp), dim3(256), 0, as_stream(stream), (const bf16_t*)A, (const bf16_t*)B, C, M,
-                           N1, N2, lda, ldb, ldc, amap, bmap, per, a_colsum, t1);
+    // to amortise the 3-unit ring fill and the register-staged kernel below is faster (192 x 192: 44 vs 54 us) -- alone; in a
+    // group launch (dkd_gemm_tn_group) the other problems' blocks cover that.
+    DkdTnProblem q = {A, B, C, a_colsum, M, N1, N2, lda, ldb, ldc, amap, bmap};
+    TnProb pl;
+    if (tn192d_plan(q, &pl, 3)) {
+      const dim3 grid(pl.tiles1 * cdiv(cdiv(M, 32), pl.units_per_split));
+      if (!pl.swap)
+        hipLaunchKernelGGL(gemm_tn192d_kernel<false>, grid, dim3(256), 0, as_stream(stream), pl.A, pl.B, pl.C, pl.M, pl.N1, pl.N2, pl.lda,
+                           pl.ldb, pl.ldc, pl.amap, pl.bmap, pl.units_per_split, pl.colsum, pl.tiles1);
       else
-        hipLaunchKernelGGL(gemm_tn192d_kernel<true>, dim3(t1 * sp), dim3(256), 0, as_stream(stream), (const bf16_t*)B, (const bf16_t*)A, C, M,
-                           N2, N1, ldb, lda, ldc, bmap, amap, per, a_colsum, t1);
+        hipLaunchKernelGGL(gemm_tn192d_kernel<true>, grid, dim3(256), 0, as_stream(stream), pl.A, pl.B, pl.C, pl.M, pl.N1, pl.N2, pl.lda,
+                           pl.ldb, pl.ldc, pl.amap, pl.bmap, pl.units_per_split, pl.colsum, pl.tiles1);
       DKD_CHECK_LAUNCH("gemm_tn192d");
       return DKD_OK;
     }

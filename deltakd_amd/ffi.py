@@ -28,6 +28,12 @@ def strip_map(tokens_per_sample: int, n_prefix: int) -> RowMap:
     return RowMap(tokens_per_sample - n_prefix, tokens_per_sample, n_prefix)
 
 
+class TnProblem(C.Structure):
+    _fields_ = [("A", C.c_void_p), ("B", C.c_void_p), ("C", C.c_void_p), ("a_colsum", C.c_void_p),
+                ("M", C.c_int32), ("N1", C.c_int32), ("N2", C.c_int32), ("lda", C.c_int32), ("ldb", C.c_int32), ("ldc", C.c_int32),
+                ("amap", RowMap), ("bmap", RowMap)]
+
+
 class Gemm(C.Structure):
     _fields_ = [
         ("A", C.c_void_p), ("B", C.c_void_p), ("C", C.c_void_p),
@@ -66,6 +72,7 @@ _SIGS = {
     "dkd_gemm_nt": (C.c_int, [C.POINTER(Gemm), C.c_void_p]),
     "dkd_gemm_tn": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                               C.c_int32, RowMap, RowMap, C.c_void_p, C.c_void_p]),
+    "dkd_gemm_tn_group": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
     "dkd_attn_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "dkd_attn_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
                                C.c_void_p]),

@@ -90,6 +90,23 @@ def gemm_tn(a, b, out, *, M=None, N1=None, N2=None, amap=IDENT, bmap=IDENT, cols
     return out
 
 
+def gemm_tn_group(problems):
+    """Up to four ``gemm_tn`` problems in one launch.  problems: sequence of dicts with the arguments of ``gemm_tn``
+    (a, b, out and optionally M, N1, N2, amap, bmap, colsum)."""
+    from .ffi import TnProblem
+    arr = (TnProblem * len(problems))()
+    for q, kw in zip(arr, problems):
+        a, b, out = kw["a"], kw["b"], kw["out"]
+        assert a.dtype == BF16 and b.dtype == BF16 and out.dtype == F32
+        q.A, q.B, q.C, q.a_colsum = ptr(a), ptr(b), ptr(out), ptr(kw.get("colsum"))
+        q.M = kw.get("M", a.shape[0])
+        q.N1, q.N2 = kw.get("N1", a.shape[1]), kw.get("N2", b.shape[1])
+        q.lda, q.ldb, q.ldc = a.stride(0), b.stride(0), out.stride(0)
+        q.amap, q.bmap = kw.get("amap", IDENT), kw.get("bmap", IDENT)
+    import ctypes
+    check(lib().dkd_gemm_tn_group(ctypes.cast(arr, ctypes.c_void_p), len(problems), stream()), "gemm_tn_group")
+
+
 def attn_fwd(qkv, B, N, H, need_lse=True):
     """qkv bf16 [B*N, 3*H*64] -> (out bf16 [B*N, H*64], lse f32 [B, H, N] | None)."""
     assert qkv.dtype == BF16 and qkv.is_contiguous() and qkv.numel() == B * N * 3 * H * 64

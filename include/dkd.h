@@ -80,6 +80,19 @@ int dkd_gemm_nt(const DkdGemm* g, void* stream);
 int dkd_gemm_tn(const void* A, const void* B, float* C, int32_t M, int32_t N1, int32_t N2, int32_t lda, int32_t ldb,
                 int32_t ldc, DkdRowMap amap, DkdRowMap bmap, float* a_colsum, void* stream);
 
+/* Up to four independent weight gradients in one launch (the two Linear layers of an MLP, or proj + qkv): same arithmetic as
+ * dkd_gemm_tn per problem, but their blocks share the GPU, so one problem's ring fill and atomic epilogue overlap another's
+ * main loop.  Problems the grouped kernel does not take (see gemm.hip) are launched on their own. */
+typedef struct DkdTnProblem {
+  const void* A;
+  const void* B;
+  float* C;
+  float* a_colsum;
+  int32_t M, N1, N2, lda, ldb, ldc;
+  DkdRowMap amap, bmap;
+} DkdTnProblem;
+int dkd_gemm_tn_group(const DkdTnProblem* problems, int32_t n, void* stream);
+
 /* ---------------------------------------------------------------- attention ([3P] F.scaled_dot_product_attention) */
 /* qkv bf16 [B, N, 3, H, 64] (the fused qkv Linear output, no head-split copy); out bf16 [B, N, H*64];
  * lse f32 [B, H, N] (natural-log sum-exp of the scaled scores, saved for backward; may be NULL). N <= 256. */

@@ -140,6 +140,33 @@ def test_gemm_tn_rowmaps(ops):
     close(out, ref, 1e-4, "tn amap")
 
 
+def test_gemm_tn_group_matches_single_launches(ops):
+    """dkd_gemm_tn_group: four weight gradients (both operand orders of the 192-wide case, a 192 x 192, and a 128-wide shape the
+    grouped kernel does not take and must launch on its own) against fp32 torch, with accumulation into non-zero outputs, fused
+    bias sums and a token-strip row map."""
+    from deltakd_amd.ffi import strip_map
+    Bn, Nt, M = 12, 66, 12 * 66
+    shapes = [(768, 192), (192, 768), (192, 192), (128, 128)]
+    probs, refs = [], []
+    for i, (n1, n2) in enumerate(shapes):
+        a = rnd(M, n1, seed=200 + i).to(BF16)
+        b = rnd(M, n2, seed=210 + i).to(BF16)
+        out = torch.full((n1, n2), 0.25, device=dev())
+        cs = torch.zeros(n1, device=dev())
+        kw = dict(a=a, b=b, out=out, colsum=cs)
+        af, bf = a.float(), b.float()
+        if i == 0:                                       # gradient of a layer fed by x[:, 2:]: rows through a strip map
+            kw.update(M=Bn * (Nt - 2), amap=strip_map(Nt, 2), bmap=strip_map(Nt, 2))
+            af = af.view(Bn, Nt, n1)[:, 2:].reshape(-1, n1)
+            bf = bf.view(Bn, Nt, n2)[:, 2:].reshape(-1, n2)
+        probs.append(kw)
+        refs.append((0.25 + af.t() @ bf, af.sum(0)))
+    ops.gemm_tn_group(probs)
+    for kw, (ref, rcs), shp in zip(probs, refs, shapes):
+        close(kw["out"], ref, 1e-4, f"group {shp}")
+        close(kw["colsum"], rcs, 1e-4, f"group colsum {shp}")
+
+
 def ref_attention(qkv, B, N, H):
     q, k, v = qkv.float().view(B, N, 3, H, 64).permute(2, 0, 3, 1, 4)
     s = (q @ k.transpose(-1, -2)) * 0.125

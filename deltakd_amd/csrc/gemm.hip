@@ -559,13 +559,24 @@ constexpr int TN_LD = 288;                 // bytes per LDS row (256 B of data +
 constexpr int TN_TILE = 64 * TN_LD;        // 18 KiB per operand tile
 __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, float* C,
                                                          int M, int N1, int N2, int lda, int ldb, int ldc, DkdRowMap amap,
-                                                         DkdRowMap bmap, int kt_per_split, float* __restrict__ a_colsum) {
+                                                         DkdRowMap bmap, int kt_per_split, float* __restrict__ a_colsum,
+                                                         int upper_only) {
   __shared__ __attribute__((aligned(16))) char smem[4 * TN_TILE];  // [buf][A|B] ; reused by the epilogue (33 KiB)
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = w >> 1, wc = w & 1;
   const int tiles2 = (N2 + 127) / 128;
-  const int t1 = blockIdx.x / tiles2, t2 = blockIdx.x % tiles2;
+  int t1 = blockIdx.x / tiles2, t2 = blockIdx.x % tiles2;
+  if (upper_only) {                      // Gram matrix: blockIdx.x enumerates the tile pairs (t1 <= t2) row by row
+    int p = blockIdx.x, row = 0, len = tiles2;
+    while (p >= len) {
+      p -= len;
+      ++row;
+      --len;
+    }
+    t1 = row;
+    t2 = row + p;
+  }
   const int n1_0 = t1 * 128, n2_0 = t2 * 128;
   const int KT_all = (M + 63) / 64;
   const int kt_begin = blockIdx.y * kt_per_split;
@@ -1357,7 +1368,23 @@ extern "C" int dkd_gemm_tn(const void* A, const void* B, float* C, int32_t M, in
   const int per = cdiv(KT, splits);
   splits = cdiv(KT, per);
   hipLaunchKernelGGL(gemm_tn_kernel, dim3(tiles, splits), dim3(256), 0, as_stream(stream), (const bf16_t*)A, (const bf16_t*)B, C, M,
-                     N1, N2, lda, ldb, ldc, amap, bmap, per, a_colsum);
+                     N1, N2, lda, ldb, ldc, amap, bmap, per, a_colsum, 0);
   DKD_CHECK_LAUNCH("gemm_tn");
+  return DKD_OK;
+}
+
+extern "C" int dkd_gram(const void* A, float* C, int32_t M, int32_t N, int32_t lda, int32_t ldc, DkdRowMap amap, void* stream) {
+  DKD_CHECK_ARG(A && C && M > 0 && N > 0, "gram: bad operand");
+  DKD_CHECK_ARG(lda % 8 == 0 && ((uintptr_t)A & 15) == 0, "gram: rows of A must be 16-byte aligned (lda=%d)", lda);
+  const int KT = cdiv(M, 64), T = cdiv(N, 128);
+  const int tiles = T * (T + 1) / 2;   // tile pairs t1 <= t2
+  int splits = cdiv(512, tiles);
+  if (splits > cdiv(KT, 4)) splits = cdiv(KT, 4);
+  if (splits < 1) splits = 1;
+  const int per = cdiv(KT, splits);
+  splits = cdiv(KT, per);
+  hipLaunchKernelGGL(gemm_tn_kernel, dim3(tiles, splits), dim3(256), 0, as_stream(stream), (const bf16_t*)A, (const bf16_t*)A, C, M, N, N,
+                     lda, lda, ldc, amap, amap, per, (float*)nullptr, 1);
+  DKD_CHECK_LAUNCH("gram");
   return DKD_OK;
 }

@@ -209,7 +209,7 @@ class LowRankTargets:
         Ts = [t.reshape(B * N, Dt) for t in taps]
         G = torch.zeros(len(Ts), Dt, Dt, device=Ts[0].device, dtype=F32)
         for i, T in enumerate(Ts):
-            ops.gemm_tn(T, T, G[i], M=B * P, amap=smap, bmap=smap)
+            ops.gram(T, G[i], M=B * P, amap=smap)           # upper-triangular tiles only, mirrored
         V = self.right_vectors(G, rank)
         out = []
         for i, T in enumerate(Ts):

@@ -90,6 +90,19 @@ def gemm_tn(a, b, out, *, M=None, N1=None, N2=None, amap=IDENT, bmap=IDENT, cols
     return out
 
 
+def gram(a, out, *, M=None, amap=IDENT):
+    """out[N, N] (f32) += a[M, N]^T a[M, N], computed on the tile pairs of the upper triangle and mirrored here (the tiles below the
+    diagonal of ``out`` must be zero on entry)."""
+    assert a.dtype == BF16 and out.dtype == F32 and out.shape[0] == out.shape[1] == a.shape[1]
+    N = a.shape[1]
+    check(lib().dkd_gram(ptr(a), ptr(out), a.shape[0] if M is None else M, N, a.stride(0), out.stride(0), amap, stream()), "gram")
+    if N > 128:
+        blk = torch.arange(N, device=out.device) // 128
+        lower = blk[:, None] > blk[None, :]                  # tiles strictly below the diagonal
+        out.copy_(torch.where(lower, out.t(), out))
+    return out
+
+
 def gemm_tn_group(problems):
     """Up to four ``gemm_tn`` problems in one launch.  problems: sequence of dicts with the arguments of ``gemm_tn``
     (a, b, out and optionally M, N1, N2, amap, bmap, colsum)."""

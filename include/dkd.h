@@ -80,6 +80,11 @@ int dkd_gemm_nt(const DkdGemm* g, void* stream);
 int dkd_gemm_tn(const void* A, const void* B, float* C, int32_t M, int32_t N1, int32_t N2, int32_t lda, int32_t ldb,
                 int32_t ldc, DkdRowMap amap, DkdRowMap bmap, float* a_colsum, void* stream);
 
+/* Upper triangle (128 x 128 tile granularity) of the Gram matrix C[N,N] += A[M,N]^T A[M,N]: the tiles below the diagonal are not
+ * touched -- the caller mirrors them (LRKD: G = T^T T of the teacher feature matrix, model/loss.py:318-321; 21 of 36 tiles for
+ * N = 768). */
+int dkd_gram(const void* A, float* C, int32_t M, int32_t N, int32_t lda, int32_t ldc, DkdRowMap amap, void* stream);
+
 /* Up to four independent weight gradients in one launch (the two Linear layers of an MLP, or proj + qkv): same arithmetic as
  * dkd_gemm_tn per problem, but their blocks share the GPU, so one problem's ring fill and atomic epilogue overlap another's
  * main loop.  Problems the grouped kernel does not take (see gemm.hip) are launched on their own. */

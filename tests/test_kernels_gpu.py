@@ -140,6 +140,21 @@ def test_gemm_tn_rowmaps(ops):
     close(out, ref, 1e-4, "tn amap")
 
 
+@pytest.mark.parametrize("M,N", [(1000, 768), (333, 128), (4 * 198, 200)])
+def test_gram_upper_triangle(ops, M, N):
+    from deltakd_amd.ffi import strip_map
+    a = rnd(M, N, seed=230).to(BF16)
+    out = torch.zeros(N, N, device=dev())
+    ops.gram(a, out)
+    ref = a.float().t() @ a.float()
+    close(out, ref, 1e-4, "gram")
+    if M == 4 * 198:
+        out2 = torch.zeros(N, N, device=dev())
+        ops.gram(a, out2, M=4 * 196, amap=strip_map(198, 2))
+        sub = a.float().view(4, 198, N)[:, 2:].reshape(-1, N)
+        close(out2, sub.t() @ sub, 1e-4, "gram strip map")
+
+
 def test_gemm_tn_group_matches_single_launches(ops):
     """dkd_gemm_tn_group: four weight gradients (both operand orders of the 192-wide case, a 192 x 192, and a 128-wide shape the
     grouped kernel does not take and must launch on its own) against fp32 torch, with accumulation into non-zero outputs, fused

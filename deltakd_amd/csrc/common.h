@@ -64,6 +64,19 @@ __device__ __forceinline__ float fast_erf(float x) {
   return copysignf(r, x);
 }
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + fast_erf(x * 0.70710678118654752f)); }
+// The same GELU without sign handling: gelu(x) = max(x, 0) - |x| q,  q = 0.5 (a1 t + ... + a5 t^5) exp(-x^2/2),
+// t = 1 / (1 + 0.3275911 |x| / sqrt 2)   (x >= 0: x - x q = x (1 + erf)/2;  x < 0: x q).  Four VALU issue slots fewer per element;
+// the bf16-output epilogue of the teacher's fc1 GEMM is bound by exactly this arithmetic.
+__device__ __forceinline__ float gelu_erf_fast(float x) {
+  const float ax = fabsf(x);
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.2316418882f, ax, 1.0f));
+  float p = fmaf(0.5307027145f, t, -0.7265760135f);
+  p = fmaf(p, t, 0.7107068705f);
+  p = fmaf(p, t, -0.142248368f);
+  p = fmaf(p, t, 0.127414796f);
+  const float e = __builtin_amdgcn_exp2f((x * -0.7213475204f) * x);
+  return fmaf(-ax, (p * t) * e, fmaxf(x, 0.f));
+}
 __device__ __forceinline__ float dgelu_erf(float x) {
   const float cdf = 0.5f * (1.0f + fast_erf(x * 0.70710678118654752f));
   const float pdf = 0.3989422804014327f * __expf(-0.5f * x * x);

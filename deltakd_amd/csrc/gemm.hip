@@ -529,7 +529,7 @@ __global__ __launch_bounds__(128 * WN, WN == 4 ? 1 : 2) void gemm_nt256_kernel(c
             f32x8 v = f32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]} + bias8[jp];
             if (FAST == 2) {
 #pragma unroll
-              for (int e = 0; e < 8; ++e) v[e] = gelu_erf(v[e]);
+              for (int e = 0; e < 8; ++e) v[e] = gelu_erf_fast(v[e]);
             }
             pk[jp] = pack8(v);
           }

@@ -331,8 +331,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const DkdGemm g, const 
 //        tiles leave 256 CUs with 2.3 rounds of work; it moves 25 % less operand data through the LDS-DMA path than the
 //        128 x 128 kernel, and the second workgroup computes while the first one's f32 residual epilogue drains.
 constexpr uint32_t vmcnt_imm(int n) { return (uint32_t)((n & 15) | ((n >> 4) << 14) | 0x0F70); }   // s_waitcnt vmcnt(n) only
-// FAST: 0 = the generic fused epilogue (runtime flags, row maps); 1 = C(bf16) = acc + bias; 2 = C(bf16) = gelu(acc + bias), both with
-// identity row maps -- the two epilogues the teacher's qkv / fc1 use, compiled without the per-vector flag tests, row-map
+// FAST: 0 = the generic fused epilogue (runtime flags, row maps); 1 = C(bf16) = acc + bias; 2 = C(bf16) = gelu(acc + bias);
+// 3 = C(f32) = resid + acc + bias (+ bf16 tap); all with identity row maps -- the two epilogues the teacher's qkv / fc1 use, compiled without the per-vector flag tests, row-map
 // divisions and spilled-SGPR reads of the generic path (they, not the GELU arithmetic, were most of the epilogue's VALU time).
 template <int ABL, int EOPS, int WN, int FAST>
 __global__ __launch_bounds__(128 * WN, WN == 4 ? 1 : 2) void gemm_nt256_kernel(const DkdGemm g, const int n_tiles) {
@@ -517,7 +517,8 @@ __global__ __launch_bounds__(128 * WN, WN == 4 ? 1 : 2) void gemm_nt256_kernel(c
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const int m = m0 + wr * 128 + i * 16 + frow;
-        if (FAST) {
+        constexpr bool FAST3 = FAST == 3;
+        if (FAST == 1 || FAST == 2) {
           // bf16 output, streaming stores of FULL 128-byte lines: a row's 64 columns of this wave sit in 4 lanes x 2 column
           // blocks; lanes of an even/odd row pair swap one block (DPP), so that one store instruction writes both halves of the
           // even row's line and the next one the odd row's.  (Half-line streaming stores wrote 30 % more bytes to memory.)
@@ -542,6 +543,26 @@ __global__ __launch_bounds__(128 * WN, WN == 4 ? 1 : 2) void gemm_nt256_kernel(c
           bf16_t* cp = (bf16_t*)g.C + (size_t)me * g.ldc + nb + (odd ? 32 : 0);
           if (me < g.M) __builtin_nontemporal_store(u32x4{d0.x, d0.y, d0.z, d0.w}, (u32x4*)cp);
           if (me + 1 < g.M) __builtin_nontemporal_store(u32x4{d1.x, d1.y, d1.z, d1.w}, (u32x4*)(cp + g.ldc));
+        } else if (FAST3) {
+          // C(f32) = resid + acc + bias, identity row maps, optional bf16 tap: 32 contiguous bytes per lane, 128 per row and block
+          if (m < g.M) {
+            const float* rp = &g.resid[(size_t)m * g.ldr + nb];
+            const f32x4 r00 = *(const f32x4*)rp, r01 = *(const f32x4*)(rp + 4), r10 = *(const f32x4*)(rp + 32), r11 = *(const f32x4*)(rp + 36);
+            const f32x8 v0 = f32x8{acc[i][0][0], acc[i][0][1], acc[i][0][2], acc[i][0][3], acc[i][1][0], acc[i][1][1], acc[i][1][2],
+                                   acc[i][1][3]} + bias8[0];
+            const f32x8 v1 = f32x8{acc[i][2][0], acc[i][2][1], acc[i][2][2], acc[i][2][3], acc[i][3][0], acc[i][3][1], acc[i][3][2],
+                                   acc[i][3][3]} + bias8[1];
+            if (g.tap) {
+              bf16_t* tp = &((bf16_t*)g.tap)[(size_t)m * g.ldt + nb];
+              *(uint4*)tp = pack8(v0);
+              *(uint4*)(tp + 32) = pack8(v1);
+            }
+            float* cp = (float*)g.C + (size_t)m * g.ldc + nb;
+            *(f32x4*)cp = r00 + f32x4{v0[0], v0[1], v0[2], v0[3]};
+            *(f32x4*)(cp + 4) = r01 + f32x4{v0[4], v0[5], v0[6], v0[7]};
+            *(f32x4*)(cp + 32) = r10 + f32x4{v1[0], v1[1], v1[2], v1[3]};
+            *(f32x4*)(cp + 36) = r11 + f32x4{v1[4], v1[5], v1[6], v1[7]};
+          }
         } else if (m < g.M) {
           EpiIn in[2];
 #pragma unroll
@@ -1232,19 +1253,45 @@ extern "C" int dkd_gemm_nt(const DkdGemm* gp, void* stream) {
   const long a_last = g.amap.rpg > 0 ? (long)((g.M - 1) / g.amap.rpg) * g.amap.gstride + (g.M - 1) % g.amap.rpg + g.amap.off : g.M - 1;
   const bool fits32 = (a_last + 1) * g.lda < (1L << 31) && (long)g.N * g.ldb < (1L << 31);   // its 32-bit source offsets
   const bool ring_ok = vec_ok && fits32 && g.K >= 512;
-  const bool wide = ring_ok && g.N % 256 == 0 && (long)cdiv(g.M, 256) * (g.N / 256) >= 1024;
+  static int n_cu = 0;
+  if (!n_cu) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) {
+      dkd_set_error("gemm_nt: cannot query the device");
+      return DKD_ERR_HIP;
+    }
+    n_cu = prop.multiProcessorCount & ~7;
+  }
+  const long t256 = g.N % 256 == 0 ? (long)cdiv(g.M, 256) * (g.N / 256) : 0;
+  bool wide = ring_ok && t256 >= 1024;
+  // N = 768 (teacher proj / fc2): 594 tiles of 256 x 256 are 2.3 rounds on 256 CUs.  The whole rounds go to the persistent kernel,
+  // the remaining rows to the 128 x 128 kernel (a second call on the row range behind them).
+  const bool fast3w = vec_ok && g.epi == (DKD_EPI_BIAS | DKD_EPI_RESID | DKD_EPI_OUT_F32) && !g.rowscale && g.amap.rpg == 0 &&
+                      g.cmap.rpg == 0 && g.rmap.rpg == 0 && !g.preact && !(g.tap && (g.epi & DKD_EPI_TAP_F32));
+  if (!wide && ring_ok && fast3w && t256 >= 2 * n_cu && t256 < 1024 && g.K >= 1536) {   // fc2: 330 -> 305 us; proj (K = 768): no gain
+    const int tn = g.N / 256;
+    const int panels1 = (int)((t256 / n_cu) * n_cu / tn);           // whole rounds' worth of 256-row panels
+    const int M1 = panels1 * 256;
+    if (M1 > 0 && M1 < g.M) {
+      DkdGemm g2 = g;
+      g2.M = g.M - M1;
+      g2.A = (const char*)g.A + (size_t)M1 * g.lda * 2;
+      g2.C = (char*)g.C + (size_t)M1 * g.ldc * 4;
+      g2.resid = g.resid + (size_t)M1 * g.ldr;
+      if (g.tap) g2.tap = (char*)g.tap + (size_t)M1 * g.ldt * 2;
+      DkdGemm g1 = g;
+      g1.M = M1;
+      {
+        ProbeScope probe1(2, 2.0 * g1.M * g1.N * g1.K, as_stream(stream));
+        hipLaunchKernelGGL((gemm_nt256_kernel<0, 0, 4, 3>), dim3(n_cu), dim3(512), 0, as_stream(stream), g1, panels1 * tn);
+        DKD_CHECK_LAUNCH("gemm_nt256");
+      }
+      return dkd_gemm_nt(&g2, stream);
+    }
+  }
   ProbeScope probe(wide ? 2 : (narrow ? 1 : 0), 2.0 * g.M * g.N * g.K, as_stream(stream));
   if (wide) {
-    static int n_cu = 0;
-    if (!n_cu) {
-      int dev = 0;
-      hipDeviceProp_t prop;
-      if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) {
-        dkd_set_error("gemm_nt: cannot query the device");
-        return DKD_ERR_HIP;
-      }
-      n_cu = prop.multiProcessorCount & ~7;
-    }
 #ifndef DKD_NT256_ABL
 #define DKD_NT256_ABL 0
 #endif

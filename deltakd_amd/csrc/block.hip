@@ -69,7 +69,7 @@ extern "C" int dkd_block_bwd(const DkdBlock* bp, const DkdBlockGrads* gp, void* 
   }
   g = mk(r.dH, b.fc1_wt, r.dT, M, D, Hd);
   TRY(dkd_gemm_nt(&g, st));
-  TRY(dkd_layernorm_bwd(r.dT, 0, b.x1, D, ID, b.ln2_w, b.mean2, b.rstd2, r.g, D, ID, 1, r.d_ln2_w, r.d_ln2_b, M, D, st));
+  TRY(dkd_layernorm_bwd(r.dT, 0, b.x1, D, ID, b.ln2_w, b.mean2, b.rstd2, r.g, D, ID, 1, r.d_ln2_w, r.d_ln2_b, M, D, r.ln_ws, st));
   // ---- attention branch
   TRY(dkd_scale_cast_bf16(r.g, D, ID, b.s1, b.N, nullptr, 1, 0, r.dF, D, M, D, st));
   g = mk(r.dF, b.proj_wt, r.dT, M, D, D);
@@ -82,6 +82,6 @@ extern "C" int dkd_block_bwd(const DkdBlock* bp, const DkdBlockGrads* gp, void* 
   }
   g = mk(r.dqkv, b.qkv_wt, r.dT, M, D, 3 * D);
   TRY(dkd_gemm_nt(&g, st));
-  TRY(dkd_layernorm_bwd(r.dT, 0, b.x, D, ID, b.ln1_w, b.mean1, b.rstd1, r.g, D, ID, 1, r.d_ln1_w, r.d_ln1_b, M, D, st));
+  TRY(dkd_layernorm_bwd(r.dT, 0, b.x, D, ID, b.ln1_w, b.mean1, b.rstd1, r.g, D, ID, 1, r.d_ln1_w, r.d_ln1_b, M, D, r.ln_ws, st));
   return DKD_OK;
 }

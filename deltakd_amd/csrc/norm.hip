@@ -84,7 +84,8 @@ template <bool DY_F32, int LPR>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy, const float* __restrict__ x, int ldx, DkdRowMap xmap,
                                                      const float* __restrict__ gamma, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, float* __restrict__ dx, int lddx, DkdRowMap dxmap,
-                                                     int accumulate, float* __restrict__ dgamma, float* __restrict__ dbeta, int M, int D) {
+                                                     int accumulate, float* __restrict__ dgamma, float* __restrict__ dbeta, int M, int D,
+                                                     float* __restrict__ part) {
   constexpr int RPW = 64 / LPR;
   __shared__ float red[2][4][LPR * 4 * MAXV];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, sl = lane % LPR, gq = lane / LPR;
@@ -162,9 +163,48 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
     }
   }
   __syncthreads();
+  // Every block adds to the same 2 D addresses (a dozen cache lines, i.e. a dozen L2 channels): with ~800 blocks the atomics
+  // serialise and were half of the kernel's time.  With a workspace the block writes its partial row instead and
+  // ln_bwd_reduce_kernel adds the rows up.
   for (int c = threadIdx.x; c < D; c += 256) {
-    atomicAdd(&dgamma[c], red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c]);
-    atomicAdd(&dbeta[c], red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c]);
+    const float pg = red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c];
+    const float pb = red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c];
+    if (part) {
+      part[(size_t)blockIdx.x * 2 * D + c] = pg;
+      part[(size_t)blockIdx.x * 2 * D + D + c] = pb;
+    } else {
+      atomicAdd(&dgamma[c], pg);
+      atomicAdd(&dbeta[c], pb);
+    }
+  }
+}
+
+// dgamma[c] += sum_b part[b][c], dbeta[c] += sum_b part[b][D + c].  grid (column groups of 64, LNR_CHUNKS row chunks): each block
+// sums its chunk of partial rows (4 waves, unrolled by 4 for loads in flight) and adds ONE value per column atomically -- 32
+// adds per address instead of one per ln_bwd block.
+constexpr int LNR_CHUNKS = 32;
+__global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restrict__ part, int nblk, float* __restrict__ dgamma,
+                                                            float* __restrict__ dbeta, int D) {
+  __shared__ float red[4][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;          // column in [0, 2 D)
+  const int per = (nblk + LNR_CHUNKS - 1) / LNR_CHUNKS;
+  const int b0 = blockIdx.y * per, b1 = min(nblk, b0 + per);
+  float s = 0.f;
+  if (c < 2 * D) {
+    int b = b0 + w;
+    for (; b + 12 < b1; b += 16) {
+      const float v0 = part[(size_t)b * 2 * D + c], v1 = part[(size_t)(b + 4) * 2 * D + c], v2 = part[(size_t)(b + 8) * 2 * D + c],
+                  v3 = part[(size_t)(b + 12) * 2 * D + c];
+      s += (v0 + v1) + (v2 + v3);
+    }
+    for (; b < b1; b += 4) s += part[(size_t)b * 2 * D + c];
+  }
+  red[w][lane] = s;
+  __syncthreads();
+  if (w == 0 && c < 2 * D && b0 < b1) {
+    const float t = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+    atomicAdd(c < D ? &dgamma[c] : &dbeta[c - D], t);
   }
 }
 
@@ -190,12 +230,12 @@ extern "C" int dkd_layernorm_fwd(const float* x, int32_t ldx, DkdRowMap xmap, co
 
 extern "C" int dkd_layernorm_bwd(const void* dy, int32_t dy_is_f32, const float* x, int32_t ldx, DkdRowMap xmap, const float* gamma,
                                  const float* mean, const float* rstd, float* dx, int32_t lddx, DkdRowMap dxmap, int32_t accumulate,
-                                 float* dgamma, float* dbeta, int32_t M, int32_t D, void* stream) {
+                                 float* dgamma, float* dbeta, int32_t M, int32_t D, float* ws, void* stream) {
   DKD_CHECK_ARG(dy && x && gamma && mean && rstd && dx && dgamma && dbeta, "layernorm_bwd: null operand");
   DKD_CHECK_ARG(M > 0 && D > 0 && D % 4 == 0 && D <= 1024 && ldx % 4 == 0 && lddx % 4 == 0, "layernorm_bwd: bad D=%d", D);
   hipStream_t st = as_stream(stream);
   const dim3 grid(cdiv(M, LNB_ROWS));
-#define LNB_ARGS dy, x, ldx, xmap, gamma, mean, rstd, dx, lddx, dxmap, accumulate, dgamma, dbeta, M, D
+#define LNB_ARGS dy, x, ldx, xmap, gamma, mean, rstd, dx, lddx, dxmap, accumulate, dgamma, dbeta, M, D, ws
   if (D <= 256) {
     if (dy_is_f32) hipLaunchKernelGGL((ln_bwd_kernel<true, 16>), grid, dim3(256), 0, st, LNB_ARGS);
     else hipLaunchKernelGGL((ln_bwd_kernel<false, 16>), grid, dim3(256), 0, st, LNB_ARGS);
@@ -205,5 +245,9 @@ extern "C" int dkd_layernorm_bwd(const void* dy, int32_t dy_is_f32, const float*
   }
 #undef LNB_ARGS
   DKD_CHECK_LAUNCH("layernorm_bwd");
+  if (ws) {
+    hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3(cdiv(2 * D, 64), LNR_CHUNKS), dim3(256), 0, st, ws, (int)grid.x, dgamma, dbeta, D);
+    DKD_CHECK_LAUNCH("layernorm_bwd_reduce");
+  }
   return DKD_OK;
 }

@@ -59,7 +59,8 @@ class Block(C.Structure):
 
 class BlockGrads(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("g", "gtap", "d_ln1_w", "d_ln1_b", "d_ln2_w", "d_ln2_b", "d_qkv_w", "d_qkv_b",
-                                          "d_proj_w", "d_proj_b", "d_fc1_w", "d_fc1_b", "d_fc2_w", "d_fc2_b", "dF", "dH", "dqkv", "dT")]
+                                          "d_proj_w", "d_proj_b", "d_fc1_w", "d_fc1_b", "d_fc2_w", "d_fc2_b", "dF", "dH", "dqkv", "dT",
+                                          "ln_ws")]
 
 
 _lib = None
@@ -81,7 +82,7 @@ _SIGS = {
                                     C.c_int32, C.c_int32, C.c_float, C.c_int32, C.c_void_p]),
     "dkd_layernorm_bwd": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, RowMap, C.c_void_p, C.c_void_p, C.c_void_p,
                                     C.c_void_p, C.c_int32, RowMap, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
-                                    C.c_void_p]),
+                                    C.c_void_p, C.c_void_p]),
     "dkd_im2col_patches": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "dkd_prefix_tokens_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "dkd_embed_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),

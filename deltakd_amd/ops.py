@@ -149,13 +149,15 @@ def layernorm_fwd(x, gamma, beta, *, M=None, xmap=IDENT, eps=1e-6, save_stats=Tr
     return y, mean, rstd
 
 
-def layernorm_bwd(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, *, M=None, xmap=IDENT, dxmap=IDENT, accumulate=False):
-    """dx (f32, in place) (+)= LN'(dy); dgamma/dbeta (f32 [D]) += ."""
+def layernorm_bwd(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, *, M=None, xmap=IDENT, dxmap=IDENT, accumulate=False, ws=None):
+    """dx (f32, in place) (+)= LN'(dy); dgamma/dbeta (f32 [D]) += .  ws: optional f32 scratch of >= 2 * D * ceil(M / 64) elements
+    (partial sums per block instead of same-address atomics)."""
     M = dy.shape[0] if M is None else M
     D = x.shape[1]
     assert dy.is_contiguous() and dy.shape[1] == D
+    assert ws is None or (ws.dtype == F32 and ws.numel() >= 2 * D * ((M + 63) // 64))
     check(lib().dkd_layernorm_bwd(ptr(dy), _is_f32(dy), ptr(x), x.stride(0), xmap, ptr(gamma), ptr(mean), ptr(rstd), ptr(dx),
-                                  dx.stride(0), dxmap, int(accumulate), ptr(dgamma), ptr(dbeta), M, D, stream()), "layernorm_bwd")
+                                  dx.stride(0), dxmap, int(accumulate), ptr(dgamma), ptr(dbeta), M, D, ptr(ws), stream()), "layernorm_bwd")
     return dx
 
 

@@ -110,10 +110,12 @@ int dkd_attn_bwd(const void* qkv, const void* out, const void* dout, const float
 /* x f32 [M, D] (rows through xmap) -> y bf16 [M, D] contiguous rows; mean/rstd f32 [M] saved when non-NULL. */
 int dkd_layernorm_fwd(const float* x, int32_t ldx, DkdRowMap xmap, const float* gamma, const float* beta, void* y,
                       float* mean, float* rstd, int32_t M, int32_t D, float eps, int32_t y_is_f32, void* stream);
-/* dx f32 [M, D] = (accumulate ? dx : 0) + LN'(dy); dgamma/dbeta f32 [D] += (atomics).  dy bf16 or f32 [M, D]. */
+/* dx f32 [M, D] = (accumulate ? dx : 0) + LN'(dy); dgamma/dbeta f32 [D] +=.  dy bf16 or f32 [M, D].
+ * ws: NULL (every block adds its partial sums atomically) or 2 * D * ceil(M / 64) floats of scratch: per-block partial rows summed by
+ * a second small launch (no same-address atomics: about a third faster at M = 50k). */
 int dkd_layernorm_bwd(const void* dy, int32_t dy_is_f32, const float* x, int32_t ldx, DkdRowMap xmap, const float* gamma,
                       const float* mean, const float* rstd, float* dx, int32_t lddx, DkdRowMap dxmap, int32_t accumulate,
-                      float* dgamma, float* dbeta, int32_t M, int32_t D, void* stream);
+                      float* dgamma, float* dbeta, int32_t M, int32_t D, float* ws, void* stream);
 
 /* ---------------------------------------------------------------- data movement / elementwise */
 /* img f32 [B, C, H, W] -> patches bf16 [B*(H/p)*(W/p), C*p*p] in Conv2d weight order (c, i, j). ([3P] PatchEmbed) */
@@ -211,6 +213,7 @@ typedef struct {
   float *d_ln1_w, *d_ln1_b, *d_ln2_w, *d_ln2_b, *d_qkv_w, *d_qkv_b, *d_proj_w, *d_proj_b, *d_fc1_w, *d_fc1_b, *d_fc2_w, *d_fc2_b;
   void *dF, *dH, *dqkv;              /* bf16 workspaces: [M, D] (also reused for dY2, dA, dO, dY1), [M, hidden], [M, 3D]  */
   void* dT;                          /* bf16 workspace [M, D]                                                            */
+  float* ln_ws;                      /* f32 scratch, 2 * D * ceil(M / 64) floats, for the LayerNorm backward partial sums; or NULL */
 } DkdBlockGrads;
 
 int dkd_blocks_fwd(const DkdBlock* blocks, int32_t n_blocks, void* stream);

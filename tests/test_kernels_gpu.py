@@ -238,6 +238,14 @@ def test_layernorm(ops, M, D):
     close(dx - 1, xr.grad, 1e-4, "ln dx")
     close(dg, gr.grad, 1e-4, "ln dgamma")
     close(db, br.grad, 1e-4, "ln dbeta")
+    # the same with per-block partial sums in a workspace (and accumulation into non-zero gradients)
+    ws = torch.empty(2 * D * ((M + 63) // 64), device=dev())
+    dx2 = torch.zeros(M, D, device=dev())
+    dg2, db2 = torch.full((D,), 0.5, device=dev()), torch.full((D,), -0.25, device=dev())
+    ops.layernorm_bwd(dy, x, gamma, mean, rstd, dx2, dg2, db2, ws=ws)
+    close(dx2, xr.grad, 1e-4, "ln dx (ws)")
+    close(dg2 - 0.5, gr.grad, 1e-4, "ln dgamma (ws)")
+    close(db2 + 0.25, br.grad, 1e-4, "ln dbeta (ws)")
 
 
 def test_im2col_and_embed(ops):

@@ -16,4 +16,6 @@ for name, M, D in (("student", 50432, 192), ("teacher", 50688, 768)):
     dx = torch.zeros(M, D, device="cuda"); dg = torch.zeros(D, device="cuda"); db = torch.zeros(D, device="cuda")
     tf = t(lambda: ops.layernorm_fwd(x, g, b))
     tb = t(lambda: ops.layernorm_bwd(dy, x, g, mean, rstd, dx, dg, db, accumulate=True))
-    print(f"{name}: fwd {tf:.1f} us ({M*D*6/tf/1e6:.2f} TB/s)  bwd {tb:.1f} us ({M*D*14/tb/1e6:.2f} TB/s)")
+    ws = torch.empty(2 * D * ((M + 63) // 64), device="cuda")
+    tw = t(lambda: ops.layernorm_bwd(dy, x, g, mean, rstd, dx, dg, db, accumulate=True, ws=ws))
+    print(f"{name}: fwd {tf:.1f} us ({M*D*6/tf/1e6:.2f} TB/s)  bwd {tb:.1f} us ({M*D*14/tb/1e6:.2f} TB/s)  bwd+ws {tw:.1f} us")

@@ -128,10 +128,10 @@ __global__ __launch_bounds__(256) void mse_loss_kernel(const void* __restrict__ 
                                                        float* __restrict__ loss, void* __restrict__ da, int da_f32, int ldda, int M, int D) {
   __shared__ float red[4];
   const int nv = D >> 2;
-  const long total = (long)M * nv;
+  const uint32_t total = (uint32_t)M * (uint32_t)nv;        // < 2^31: checked on the host (64-bit division per element is slow)
   float acc = 0.f;
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int m = (int)(i / nv), c = (int)(i % nv) * 4;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int m = (int)(i / (uint32_t)nv), c = (int)(i % (uint32_t)nv) * 4;
     const f32x4 av = load4(a, a_f32, (size_t)m * lda + c);
     const f32x4 tv = load4(t, t_f32, (size_t)map_row(tmap, m) * ldt + c);
     const float mk = mask ? mask[m] : 1.f;
@@ -208,7 +208,9 @@ extern "C" int dkd_mse_loss(const void* a, int32_t a_is_f32, int32_t lda, const 
                             int32_t D, void* stream) {
   DKD_CHECK_ARG(a && t && loss && M > 0 && D > 0, "mse_loss: null operand");
   DKD_CHECK_ARG(D % 4 == 0 && lda % 4 == 0 && ldt % 4 == 0 && (!da || ldda % 4 == 0), "mse_loss: D/ld must be multiples of 4");
-  hipLaunchKernelGGL(mse_loss_kernel, dim3(grid_for((long)M * D / 4, 256, 2048)), dim3(256), 0, as_stream(stream), a, a_is_f32, lda, t,
+  DKD_CHECK_ARG((long)M * (D / 4) < (1L << 31), "mse_loss: M * D / 4 must be below 2^31");
+  // every block ends with one atomic on the SAME address (~23 ns each, serialised): 512 blocks, not 2048
+  hipLaunchKernelGGL(mse_loss_kernel, dim3(grid_for((long)M * D / 4, 256, 512)), dim3(256), 0, as_stream(stream), a, a_is_f32, lda, t,
                      t_is_f32, ldt, tmap, mask, w_over_denom, loss, da, da_is_f32, ldda, M, D);
   DKD_CHECK_LAUNCH("mse_loss");
   return DKD_OK;

@@ -8,7 +8,7 @@ WRITE_SIZE is exact (MI355X_MICROARCH.md, HBM / rocprofv3 section).
 import collections, csv, glob, json, os, re, sys
 
 root, config, out = sys.argv[1], sys.argv[2], sys.argv[3]
-KEYS = ("gemm_nt_kernel<64", "gemm_nt_kernel<128", "gemm_nt256_kernel", "gemm_tn_kernel", "gemm_tn192_kernel", "gemm_tn192d_kernel",
+KEYS = ("gemm_nt_kernel<64", "gemm_nt_kernel<128", "gemm_nt256_kernel", "gemm_tn_kernel", "gemm_tn192g_kernel", "gemm_tn192d_kernel", "gemm_tn192_kernel", "attn_fwd_ring_kernel",
         "attn_fwd_kernel", "attn_bwd_dq_kernel", "attn_bwd_dkv_kernel", "ln_fwd_kernel", "ln_bwd_kernel")
 
 

@@ -77,6 +77,19 @@ __device__ __forceinline__ float gelu_erf_fast(float x) {
   const float e = __builtin_amdgcn_exp2f((x * -0.7213475204f) * x);
   return fmaf(-ax, (p * t) * e, fmaxf(x, 0.f));
 }
+// gelu'(x) = Phi(x) + x phi(x) with ONE exponential: exp(-x^2/2) serves both the A&S erf tail (q, as in gelu_erf_fast) and phi.
+__device__ __forceinline__ float dgelu_erf_fast(float x) {
+  const float ax = fabsf(x);
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.2316418882f, ax, 1.0f));
+  float p = fmaf(0.5307027145f, t, -0.7265760135f);
+  p = fmaf(p, t, 0.7107068705f);
+  p = fmaf(p, t, -0.142248368f);
+  p = fmaf(p, t, 0.127414796f);
+  const float e = __builtin_amdgcn_exp2f((x * -0.7213475204f) * x);
+  const float q = (p * t) * e;                       // 1 - Phi(|x|)
+  const float cdf = x >= 0.f ? 1.0f - q : q;
+  return fmaf(x * 0.3989422804f, e, cdf);
+}
 __device__ __forceinline__ float dgelu_erf(float x) {
   const float cdf = 0.5f * (1.0f + fast_erf(x * 0.70710678118654752f));
   const float pdf = 0.3989422804014327f * __expf(-0.5f * x * x);

@@ -162,6 +162,48 @@ __device__ __forceinline__ void nt_epilogue(const DkdGemm& g, const int vec_ok, 
   const int col8 = (tid % TPR) * 8, r0 = tid / TPR;
   const int n = n0 + col8;
   if (n >= g.N) return;
+  if (FAST == 1 || FAST == 4 || FAST == 5 || FAST == 6) {
+    // bf16 outputs with identity row maps: 1: C = acc + bias;  4: preact = acc + bias, C = gelu(preact);  5: C = acc * gelu'(preact);
+    // 6: C = acc
+    constexpr int SW = 64 / RPP;
+    f32x8 b8 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (FAST != 5 && FAST != 6) {
+      const f32x4 b0 = *(const f32x4*)&g.bias[n], b1 = *(const f32x4*)&g.bias[n + 4];
+      b8 = f32x8{b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+    }
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      uint4 pre[SW];
+      if (FAST == 5) {
+#pragma unroll
+        for (int s = 0; s < SW; ++s) {
+          const int m = m0 + half * 64 + r0 + RPP * s;
+          if (m < g.M) pre[s] = *(const uint4*)&((const bf16_t*)g.preact)[(size_t)m * g.ldp + n];
+        }
+      }
+#pragma unroll
+      for (int s = 0; s < SW; ++s) {
+        const int rl = half * 64 + r0 + RPP * s;
+        const int m = m0 + rl;
+        if (m < g.M) {
+          const f32x4 lo = *(const f32x4*)&cs[rl * BN + col8], hi = *(const f32x4*)&cs[rl * BN + col8 + 4];
+          f32x8 v = f32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]} + b8;
+          if (FAST == 4) {
+            *(uint4*)&((bf16_t*)g.preact)[(size_t)m * g.ldp + n] = pack8(v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = gelu_erf_fast(v[e]);
+          }
+          if (FAST == 5) {
+            const f32x8 p = unpack8(pre[s]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] *= dgelu_erf_fast(p[e]);
+          }
+          *(uint4*)((bf16_t*)g.C + (size_t)m * g.ldc + n) = pack8(v);
+        }
+      }
+    }
+    return;
+  }
   if (FAST == 3) {
     constexpr int SW = 64 / RPP;
     const f32x4 b0 = *(const f32x4*)&g.bias[n], b1 = *(const f32x4*)&g.bias[n + 4];
@@ -1308,14 +1350,33 @@ extern "C" int dkd_gemm_nt(const DkdGemm* gp, void* stream) {
     DKD_CHECK_LAUNCH("gemm_nt256");
     return DKD_OK;
   }
+  // compile-time epilogues for the most frequent plain cases (identity row maps, 16-byte aligned operands): see nt_epilogue
+  const bool ident = vec_ok && g.amap.rpg >= 0 && g.cmap.rpg == 0 && !g.rowscale && !g.tap && !g.resid;
+  int fast = 0;
+  if (ident && g.N % 8 == 0) {
+    if (g.epi == DKD_EPI_BIAS && !g.preact) fast = 1;
+    else if (g.epi == (DKD_EPI_BIAS | DKD_EPI_GELU) && g.preact) fast = 4;
+    else if (g.epi == DKD_EPI_DGELU) fast = 5;
+    else if (g.epi == 0 && !g.preact) fast = 6;
+  }
+#define NT_LAUNCH(BN_, F_) hipLaunchKernelGGL((gemm_nt_kernel<BN_, F_>), dim3(tiles_m * cdiv(g.N, BN_)), dim3(256), 0, as_stream(stream), g, vec_ok)
   if (narrow) {
-    hipLaunchKernelGGL((gemm_nt_kernel<64, 0>), dim3(tiles_m * cdiv(g.N, 64)), dim3(256), 0, as_stream(stream), g, vec_ok);
+    if (fast == 1) NT_LAUNCH(64, 1);
+    else if (fast == 4) NT_LAUNCH(64, 4);
+    else if (fast == 5) NT_LAUNCH(64, 5);
+    else if (fast == 6) NT_LAUNCH(64, 6);
+    else NT_LAUNCH(64, 0);
   } else {
     const bool fast3 = vec_ok && g.N % 128 == 0 && g.epi == (DKD_EPI_BIAS | DKD_EPI_RESID | DKD_EPI_OUT_F32) && !g.rowscale &&
                        g.cmap.rpg == 0 && g.rmap.rpg == 0 && !g.preact && !(g.tap && (g.epi & DKD_EPI_TAP_F32));
-    if (fast3) hipLaunchKernelGGL((gemm_nt_kernel<128, 3>), dim3(tiles_m * cdiv(g.N, 128)), dim3(256), 0, as_stream(stream), g, vec_ok);
-    else hipLaunchKernelGGL((gemm_nt_kernel<128, 0>), dim3(tiles_m * cdiv(g.N, 128)), dim3(256), 0, as_stream(stream), g, vec_ok);
+    if (fast3) NT_LAUNCH(128, 3);
+    else if (fast == 1) NT_LAUNCH(128, 1);
+    else if (fast == 4) NT_LAUNCH(128, 4);
+    else if (fast == 5) NT_LAUNCH(128, 5);
+    else if (fast == 6) NT_LAUNCH(128, 6);
+    else NT_LAUNCH(128, 0);
   }
+#undef NT_LAUNCH
   DKD_CHECK_LAUNCH("gemm_nt");
   return DKD_OK;
 }

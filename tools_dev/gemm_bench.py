@@ -8,7 +8,7 @@ dev = "cuda:0"
 BF16 = torch.bfloat16
 shapes = [  # (name, M, N, K, epilogue)
     ("t_qkv", 50688, 2304, 768, "bias"), ("t_proj", 50688, 768, 768, "resid"), ("t_fc1", 50688, 3072, 768, "gelu"),
-    ("t_fc2", 50688, 768, 3072, "resid"), ("s_qkv", 50432, 576, 192, "bias"), ("s_fc1", 50432, 768, 192, "gelu"),
+    ("t_fc2", 50688, 768, 3072, "resid"), ("s_qkv", 50432, 576, 192, "bias"), ("s_fc1", 50432, 768, 192, "gelu"), ("s_fc1p", 50432, 768, 192, "gelu_pre"), ("s_fc2d", 50432, 768, 192, "dgelu"),
     ("s_fc2", 50432, 192, 768, "resid"), ("s_proj", 50432, 192, 192, "resid"),
 ]
 only = sys.argv[1:] 
@@ -22,6 +22,10 @@ for name, M, N, K, epi in shapes:
     kw = dict(bias=bias)
     if epi == "gelu":
         kw.update(gelu=True)
+    if epi == "gelu_pre":
+        kw.update(gelu=True, preact=torch.empty(M, N, device=dev, dtype=BF16))
+    if epi == "dgelu":
+        kw = dict(dgelu=True, preact=torch.randn(M, N, device=dev).to(BF16))
     if epi == "resid":
         kw.update(resid=torch.randn(M, N, device=dev), out_f32=True)
     out = ops.gemm_nt(a, b, **kw)
@@ -40,9 +44,13 @@ for name, M, N, K, epi in shapes:
 # correctness spot check of the last shape
 if res:
     epi, kw, a_, b_, bias, out_ = last
-    ref = a_[-512:].float() @ b_.float().t() + bias
-    if epi == "gelu":
+    ref = a_[-512:].float() @ b_.float().t() + (0 if epi == "dgelu" else bias)
+    if epi in ("gelu", "gelu_pre"):
         ref = torch.nn.functional.gelu(ref)
+    if epi == "dgelu":
+        p_ = kw["preact"][-512:].float().requires_grad_(True)
+        torch.nn.functional.gelu(p_).sum().backward()
+        ref = ref * p_.grad
     if epi == "resid":
         ref = ref + kw["resid"][-512:]
     err = (out_[-512:].float() - ref).abs().max().item() / ref.abs().max().item()

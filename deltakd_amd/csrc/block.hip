@@ -62,7 +62,8 @@ extern "C" int dkd_block_bwd(const DkdBlock* bp, const DkdBlockGrads* gp, void* 
   DkdGemm g = mk(r.dF, b.fc2_wt, r.dH, M, Hd, D);
   g.epi = DKD_EPI_DGELU; g.preact = b.pre; g.ldp = Hd;
   TRY(dkd_gemm_nt(&g, st));
-  {                                     // both MLP weight gradients in one launch (dF is not overwritten before the attention branch)
+  const bool all4 = r.dF2 != nullptr;   // a second [M, D] buffer keeps the MLP branch's dF alive: all four weight gradients go out together
+  if (!all4) {                          // both MLP weight gradients in one launch (dF is not overwritten before the attention branch)
     const DkdTnProblem w[2] = {{r.dF, b.h, r.d_fc2_w, r.d_fc2_b, M, D, Hd, D, Hd, Hd, ID, ID},
                                {r.dH, b.y2, r.d_fc1_w, r.d_fc1_b, M, Hd, D, Hd, D, D, ID, ID}};
     TRY(dkd_gemm_tn_group(w, 2, st));
@@ -71,12 +72,19 @@ extern "C" int dkd_block_bwd(const DkdBlock* bp, const DkdBlockGrads* gp, void* 
   TRY(dkd_gemm_nt(&g, st));
   TRY(dkd_layernorm_bwd(r.dT, 0, b.x1, D, ID, b.ln2_w, b.mean2, b.rstd2, r.g, D, ID, 1, r.d_ln2_w, r.d_ln2_b, M, D, r.ln_ws, st));
   // ---- attention branch
-  TRY(dkd_scale_cast_bf16(r.g, D, ID, b.s1, b.N, nullptr, 1, 0, r.dF, D, M, D, st));
-  g = mk(r.dF, b.proj_wt, r.dT, M, D, D);
+  void* dFa = all4 ? r.dF2 : r.dF;      // gradient w.r.t. the attention branch's output (bf16)
+  TRY(dkd_scale_cast_bf16(r.g, D, ID, b.s1, b.N, nullptr, 1, 0, dFa, D, M, D, st));
+  g = mk(dFa, b.proj_wt, r.dT, M, D, D);
   TRY(dkd_gemm_nt(&g, st));
   TRY(dkd_attn_bwd(b.qkv, b.o, r.dT, b.lse, r.dqkv, b.B, b.N, b.H, st));
-  {                                     // proj and qkv weight gradients in one launch
-    const DkdTnProblem w[2] = {{r.dF, b.o, r.d_proj_w, r.d_proj_b, M, D, D, D, D, D, ID, ID},
+  if (all4) {
+    const DkdTnProblem w[4] = {{r.dF, b.h, r.d_fc2_w, r.d_fc2_b, M, D, Hd, D, Hd, Hd, ID, ID},
+                               {r.dH, b.y2, r.d_fc1_w, r.d_fc1_b, M, Hd, D, Hd, D, D, ID, ID},
+                               {dFa, b.o, r.d_proj_w, r.d_proj_b, M, D, D, D, D, D, ID, ID},
+                               {r.dqkv, b.y1, r.d_qkv_w, r.d_qkv_b, M, 3 * D, D, 3 * D, D, D, ID, ID}};
+    TRY(dkd_gemm_tn_group(w, 4, st));
+  } else {                              // proj and qkv weight gradients in one launch
+    const DkdTnProblem w[2] = {{dFa, b.o, r.d_proj_w, r.d_proj_b, M, D, D, D, D, D, ID, ID},
                                {r.dqkv, b.y1, r.d_qkv_w, r.d_qkv_b, M, 3 * D, D, 3 * D, D, D, ID, ID}};
     TRY(dkd_gemm_tn_group(w, 2, st));
   }

@@ -1427,7 +1427,8 @@ extern "C" int dkd_gemm_tn_group(const DkdTnProblem* probs, int32_t n, void* str
     DKD_CHECK_ARG(q.A && q.B && q.C && q.M > 0 && q.N1 > 0 && q.N2 > 0, "gemm_tn_group: bad problem %d", i);
     // in a group the other problems supply the parallelism: 192 blocks per problem halve the atomically added partial tiles
     // (student-only step: 27.0k img/s at 384, 27.8k at 256, 29.1k at 192, 27.6k at 128)
-    if (tn192d_plan(q, &grp.p[grp.n], 1, n > 1 ? 192 : 384)) {
+    // ... and 96 each with four (29.6k / 29.5k / 30.5k / 29.0k img/s at 192 / 128 / 96 / 64)
+    if (tn192d_plan(q, &grp.p[grp.n], 1, n > 2 ? 96 : (n > 1 ? 192 : 384))) {
       total += grp.p[grp.n].n_blocks;
       ++grp.n;
     } else {                            // shapes the ring kernel does not take: launched on their own

@@ -60,7 +60,7 @@ class Block(C.Structure):
 class BlockGrads(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("g", "gtap", "d_ln1_w", "d_ln1_b", "d_ln2_w", "d_ln2_b", "d_qkv_w", "d_qkv_b",
                                           "d_proj_w", "d_proj_b", "d_fc1_w", "d_fc1_b", "d_fc2_w", "d_fc2_b", "dF", "dH", "dqkv", "dT",
-                                          "ln_ws")]
+                                          "ln_ws", "dF2")]
 
 
 _lib = None

@@ -233,7 +233,7 @@ def _block_forward_train(x, B, N, blk: Block, sh: Shadow, s1, s2, want_tap: bool
 
 def _backward_workspace(model, M, D, Hd, dev):
     ws = getattr(model, "_bwd_ws", None)
-    need = _bytes_al(M * D, 2) * 2 + _bytes_al(M * Hd, 2) + _bytes_al(M * 3 * D, 2) + _bytes_al(2 * D * ((M + 63) // 64), 4)
+    need = _bytes_al(M * D, 2) * 3 + _bytes_al(M * Hd, 2) + _bytes_al(M * 3 * D, 2) + _bytes_al(2 * D * ((M + 63) // 64), 4)
     if ws is None or ws.numel() < need or ws.device != dev:
         ws = torch.empty(need, device=dev, dtype=torch.uint8)
         model._bwd_ws = ws
@@ -254,6 +254,7 @@ def _block_backward(g, gtap, model, blk: Block, saved):
     gr.dH = gr.dT + _bytes_al(M * D, 2)
     gr.dqkv = gr.dH + _bytes_al(M * Hd, 2)
     gr.ln_ws = gr.dqkv + _bytes_al(M * 3 * D, 2)       # LayerNorm backward: per-block partial sums (no same-address atomics)
+    gr.dF2 = gr.ln_ws + _bytes_al(2 * D * ((M + 63) // 64), 4)   # keeps the MLP branch's dF alive: one launch for all 4 wgrads
     a, m = blk.attn, blk.mlp
     gr.d_ln1_w, gr.d_ln1_b = ensure_grad(blk.norm1.weight).data_ptr(), ensure_grad(blk.norm1.bias).data_ptr()
     gr.d_ln2_w, gr.d_ln2_b = ensure_grad(blk.norm2.weight).data_ptr(), ensure_grad(blk.norm2.bias).data_ptr()

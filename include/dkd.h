@@ -214,6 +214,7 @@ typedef struct {
   void *dF, *dH, *dqkv;              /* bf16 workspaces: [M, D] (also reused for dY2, dA, dO, dY1), [M, hidden], [M, 3D]  */
   void* dT;                          /* bf16 workspace [M, D]                                                            */
   float* ln_ws;                      /* f32 scratch, 2 * D * ceil(M / 64) floats, for the LayerNorm backward partial sums; or NULL */
+  void* dF2;                         /* second bf16 [M, D] workspace or NULL: with it all four weight gradients are one launch   */
 } DkdBlockGrads;
 
 int dkd_blocks_fwd(const DkdBlock* blocks, int32_t n_blocks, void* stream);

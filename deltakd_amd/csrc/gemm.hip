@@ -377,7 +377,7 @@ constexpr uint32_t vmcnt_imm(int n) { return (uint32_t)((n & 15) | ((n >> 4) << 
 // 3 = C(f32) = resid + acc + bias (+ bf16 tap); all with identity row maps -- the two epilogues the teacher's qkv / fc1 use, compiled without the per-vector flag tests, row-map
 // divisions and spilled-SGPR reads of the generic path (they, not the GELU arithmetic, were most of the epilogue's VALU time).
 template <int ABL, int EOPS, int WN, int FAST>
-__global__ __launch_bounds__(128 * WN, WN == 4 ? 1 : 2) void gemm_nt256_kernel(const DkdGemm g, const int n_tiles, const int order2d) {
+__global__ __launch_bounds__(128 * WN, WN == 4 ? 1 : 2) void gemm_nt256_kernel(const DkdGemm g, const int n_tiles) {
   constexpr int BN = 64 * WN, NW = 2 * WN;          // tile columns, waves
   constexpr int WHALF = 16384, UNIT = WHALF + BN * 64, RING = WN == 4 ? 5 : 3;
   constexpr int AP = 8 / WN, PIECES = AP + 2;       // 1-KiB LDS-DMA pieces per wave per unit: A rows, then 2 of W rows
@@ -393,26 +393,12 @@ __global__ __launch_bounds__(128 * WN, WN == 4 ? 1 : 2) void gemm_nt256_kernel(c
   // of W); the chunk is dealt round-robin to the XCD's resident blocks
   const int x = blockIdx.x & 7, slot_in_xcd = blockIdx.x >> 3, nslots = gridDim.x >> 3;
   const int tq = n_tiles >> 3, tr = n_tiles & 7;
-  int chunk_begin = x < tr ? x * (tq + 1) : tr * (tq + 1) + (x - tr) * tq;
-  int chunk_cnt = tq + (x < tr ? 1 : 0);
-  // order2d: the XCDs form a 4 x 2 grid over (row panels, column tiles) instead of 8 row ranges.  An XCD then only ever touches
-  // half of W (qkv: 5 of 9 tiles, 2 MB), which stays in its 4-MiB L2 across rounds -- with all of W (3.5-4.7 MB) plus the A
-  // panels streaming through, W was re-fetched from the Infinity Cache every round.  Row panels are taken in pairs ("super
-  // rows"); the 2 * tiles_n tiles of a pair, ordered column-major, are split evenly between the two XCDs of a row range.
-  const int sr0 = order2d ? (x >> 1) * (n_tiles / tiles_n / 2) / 4 : 0, sr1 = order2d ? ((x >> 1) + 1) * (n_tiles / tiles_n / 2) / 4 : 0;
-  if (order2d) {
-    chunk_begin = 0;
-    chunk_cnt = (sr1 - sr0) * tiles_n;
-  }
+  const int chunk_begin = x < tr ? x * (tq + 1) : tr * (tq + 1) + (x - tr) * tq;
+  const int chunk_cnt = tq + (x < tr ? 1 : 0);
   const int my_tiles = slot_in_xcd < chunk_cnt ? (chunk_cnt - slot_in_xcd + nslots - 1) / nslots : 0;
   if (my_tiles == 0) return;
   const int total_units = my_tiles * P;
-  auto tile_of = [&](int k) {
-    const int j = slot_in_xcd + k * nslots;
-    if (!order2d) return chunk_begin + j;
-    const int sr = sr0 + j / tiles_n, t = (x & 1) * tiles_n + j % tiles_n;
-    return (2 * sr + (t & 1)) * tiles_n + (t >> 1);
-  };
+  auto tile_of = [&](int k) { return chunk_begin + slot_in_xcd + k * nslots; };
 
   // ---- load cursor (runs RING units ahead of the multiply cursor)
   const bf16_t* Ab = (const bf16_t*)g.A;
@@ -1340,7 +1326,7 @@ extern "C" int dkd_gemm_nt(const DkdGemm* gp, void* stream) {
       g1.M = M1;
       {
         ProbeScope probe1(2, 2.0 * g1.M * g1.N * g1.K, as_stream(stream));
-        hipLaunchKernelGGL((gemm_nt256_kernel<0, 0, 4, 3>), dim3(n_cu), dim3(512), 0, as_stream(stream), g1, panels1 * tn, 0);
+        hipLaunchKernelGGL((gemm_nt256_kernel<0, 0, 4, 3>), dim3(n_cu), dim3(512), 0, as_stream(stream), g1, panels1 * tn);
         DKD_CHECK_LAUNCH("gemm_nt256");
       }
       return dkd_gemm_nt(&g2, stream);
@@ -1353,19 +1339,14 @@ extern "C" int dkd_gemm_nt(const DkdGemm* gp, void* stream) {
 #endif
     const int n_tiles = cdiv(g.M, 256) * (g.N / 256);
     const dim3 grid(n_cu);               // persistent: one workgroup per CU, tiles dealt per XCD inside the kernel
-    // 2-D XCD order (see the kernel) when it does not raise the largest per-CU tile count: fc1 (12 column tiles) 321 -> 312 us;
-    // qkv (9) would go from 7 to 8 tiles on some CUs and lose 10 %.
-    const int pm = cdiv(g.M, 256), tn = g.N / 256, slots = n_cu / 8;
-    const int max1d = cdiv(cdiv(n_tiles, 8), slots), max2d = cdiv(cdiv(pm / 2, 4) * tn, slots);
-    const int order2d = (pm % 2 == 0 && pm >= 64 && max2d <= max1d) ? 1 : 0;
     // bf16 C and nothing else written or read by the epilogue: 16 stores per wave per tile, counted exactly by the waits
     const bool plain16 = !(g.epi & (DKD_EPI_RESID | DKD_EPI_DGELU | DKD_EPI_OUT_F32)) && !g.tap && !g.preact;
     const bool ident = g.cmap.rpg == 0 && !g.rowscale && (g.epi & DKD_EPI_BIAS);
     const int fast = !(plain16 && ident) ? 0 : (g.epi == DKD_EPI_BIAS ? 1 : (g.epi == (DKD_EPI_BIAS | DKD_EPI_GELU) ? 2 : 0));
-    if (fast == 1) hipLaunchKernelGGL((gemm_nt256_kernel<DKD_NT256_ABL, 16, 4, 1>), grid, dim3(512), 0, as_stream(stream), g, n_tiles, order2d);
-    else if (fast == 2) hipLaunchKernelGGL((gemm_nt256_kernel<DKD_NT256_ABL, 16, 4, 2>), grid, dim3(512), 0, as_stream(stream), g, n_tiles, order2d);
-    else if (plain16) hipLaunchKernelGGL((gemm_nt256_kernel<DKD_NT256_ABL, 16, 4, 0>), grid, dim3(512), 0, as_stream(stream), g, n_tiles, order2d);
-    else hipLaunchKernelGGL((gemm_nt256_kernel<DKD_NT256_ABL, 0, 4, 0>), grid, dim3(512), 0, as_stream(stream), g, n_tiles, order2d);
+    if (fast == 1) hipLaunchKernelGGL((gemm_nt256_kernel<DKD_NT256_ABL, 16, 4, 1>), grid, dim3(512), 0, as_stream(stream), g, n_tiles);
+    else if (fast == 2) hipLaunchKernelGGL((gemm_nt256_kernel<DKD_NT256_ABL, 16, 4, 2>), grid, dim3(512), 0, as_stream(stream), g, n_tiles);
+    else if (plain16) hipLaunchKernelGGL((gemm_nt256_kernel<DKD_NT256_ABL, 16, 4, 0>), grid, dim3(512), 0, as_stream(stream), g, n_tiles);
+    else hipLaunchKernelGGL((gemm_nt256_kernel<DKD_NT256_ABL, 0, 4, 0>), grid, dim3(512), 0, as_stream(stream), g, n_tiles);
     DKD_CHECK_LAUNCH("gemm_nt256");
     return DKD_OK;
   }

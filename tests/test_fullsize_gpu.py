@@ -173,3 +173,22 @@ def test_lowrank_targets_properties_full_size(ops):
     assert rel((tg @ V.t()) @ V, tg) < 2e-2                   # projection is idempotent
     res = [(patches - (patches @ V[:, :k]) @ V[:, :k].t()).pow(2).sum().item() for k in (16, 32, 64)]
     assert res[0] > res[1] > res[2] > 0
+
+
+@pytest.mark.parametrize("epi", ["bias", "gelu"])
+def test_wide_gemm_ragged_rows(ops, epi):
+    """The persistent 256 x 256 kernel on an M that is odd and not a multiple of 256 (edge tiles: clamped A rows, masked stores, the
+    even/odd row-pair exchange of the full-line store with its odd partner missing)."""
+    M, N, K = 30001, 2304, 768
+    a = rnd(M, K, seed=21).to(BF16)
+    w = rnd(N, K, scale=0.05, seed=22).to(BF16)
+    bias = rnd(N, seed=23)
+    canary = torch.full((M + 8, N), 7.0, device=DEV, dtype=BF16)
+    out = canary[:M]
+    ops.gemm_nt(a, w, out=out, bias=bias, gelu=(epi == "gelu"))
+    assert torch.all(canary[M:] == 7.0), "rows past M were written"
+    for lo, hi in ((0, 257), (15000, 15300), (M - 300, M)):
+        ref = a[lo:hi].float() @ w.float().t() + bias
+        if epi == "gelu":
+            ref = torch.nn.functional.gelu(ref)
+        assert rel(out[lo:hi], ref) < 1e-2, (epi, lo)

@@ -83,6 +83,39 @@ __global__ void cast_weight_kernel(const float* __restrict__ w, bf16_t* __restri
   }
 }
 
+// The same for a whole table of matrices in one launch (the transposed shadows of every student weight after an optimizer step:
+// ~50 matrices of 37k-150k elements, each too small to fill the GPU and ~5 us as a launch of its own).
+// items (device memory): n records {w, wt, rows, cols, first_tile}; first_tile[i] = sum of ceil(rows/32)*ceil(cols/32) before i.
+__global__ void cast_weight_group_kernel(const DkdCastItem* __restrict__ items, int n) {
+  __shared__ bf16_t tile[32][33];
+  __shared__ int which;
+  if (threadIdx.x == 0) {
+    int lo = 0, hi = n - 1;                       // last item whose first_tile <= blockIdx.x
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (items[mid].first_tile <= (int)blockIdx.x) lo = mid;
+      else hi = mid - 1;
+    }
+    which = lo;
+  }
+  __syncthreads();
+  const DkdCastItem it = items[which];
+  const int t = blockIdx.x - it.first_tile, tcols = (it.cols + 31) >> 5;
+  const int r0 = (t / tcols) * 32, c0 = (t % tcols) * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const float* w = it.w;
+  bf16_t* wt = (bf16_t*)it.wt;
+  for (int i = ty; i < 32; i += 8) {
+    const int r = r0 + i, c = c0 + tx;
+    if (r < it.rows && c < it.cols) tile[i][tx] = f2bf(w[(size_t)r * it.cols + c]);
+  }
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8) {
+    const int c = c0 + i, r = r0 + tx;
+    if (r < it.rows && c < it.cols) wt[(size_t)c * it.rows + r] = tile[tx][i];
+  }
+}
+
 // out[n] += sum_m x[xmap(m), n]   grid = (ceil(N/64), row splits); block 256 = 4 row-lanes x 64 columns
 template <bool X_F32>
 __global__ void colsum_kernel(const void* __restrict__ x, int ldx, DkdRowMap xmap, float* __restrict__ out, int M, int N, int rows_per_block) {
@@ -225,6 +258,13 @@ extern "C" int dkd_cast_weight(const float* w, void* w_bf16, void* w_t_bf16, int
   hipLaunchKernelGGL(cast_weight_kernel, dim3(cdiv(cols, 32), cdiv(rows, 32)), dim3(256), 0, as_stream(stream), w, (bf16_t*)w_bf16,
                      (bf16_t*)w_t_bf16, rows, cols);
   DKD_CHECK_LAUNCH("cast_weight");
+  return DKD_OK;
+}
+
+extern "C" int dkd_cast_weight_group(const DkdCastItem* items_dev, int32_t n, int32_t total_tiles, void* stream) {
+  DKD_CHECK_ARG(items_dev && n > 0 && total_tiles > 0, "cast_weight_group: bad arguments");
+  hipLaunchKernelGGL(cast_weight_group_kernel, dim3(total_tiles), dim3(256), 0, as_stream(stream), items_dev, n);
+  DKD_CHECK_LAUNCH("cast_weight_group");
   return DKD_OK;
 }
 

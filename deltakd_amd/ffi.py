@@ -89,6 +89,7 @@ _SIGS = {
     "dkd_scale_cast_bf16": (C.c_int, [C.c_void_p, C.c_int32, RowMap, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32,
                                       C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "dkd_cast_weight": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
+    "dkd_cast_weight_group": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "dkd_colsum": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, RowMap, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "dkd_add_rows": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, RowMap, C.c_int32, C.c_int32, C.c_int32,
                                C.c_void_p]),

@@ -197,6 +197,24 @@ def cast_weight(w, w_bf16=None, w_t_bf16=None):
     check(lib().dkd_cast_weight(ptr(w), ptr(w_bf16), ptr(w_t_bf16), rows, cols, stream()), "cast_weight")
 
 
+def cast_weight_table(pairs):
+    """Device-side table for ``cast_weight_group``: pairs = [(w f32 [rows, cols] contiguous, wt bf16 [cols, rows])] ->
+    (int64 tensor of DkdCastItem records, n, total_tiles).  Keep it as long as the tensors in ``pairs`` live."""
+    rec, tiles = [], 0
+    for w, wt in pairs:
+        rows = w.shape[0]
+        cols = w.numel() // rows
+        assert w.dtype == F32 and w.is_contiguous() and wt.dtype == BF16 and wt.is_contiguous() and wt.numel() == w.numel()
+        rec += [w.data_ptr(), wt.data_ptr(), rows | (cols << 32), tiles]           # {w, wt, rows, cols, first_tile, pad}
+        tiles += ((rows + 31) // 32) * ((cols + 31) // 32)
+    return torch.tensor(rec, dtype=torch.int64, device=pairs[0][0].device), len(pairs), tiles
+
+
+def cast_weight_group(table):
+    tab, n, tiles = table
+    check(lib().dkd_cast_weight_group(ptr(tab), n, tiles, stream()), "cast_weight_group")
+
+
 def colsum(x, out, *, M=None, N=None, xmap=IDENT):
     M = x.shape[0] if M is None else M
     N = x.shape[1] if N is None else N

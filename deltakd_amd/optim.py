@@ -114,6 +114,8 @@ class FusedAdamW(torch.optim.Optimizer):
                            self._step)
         for sh in self._shadows:
             sh.optimizer_stepped(bf16_fresh=True)
+            if hasattr(sh, "refresh_transposed"):
+                sh.refresh_transposed()
 
     # ---- checkpoint wire format: torch.optim.AdamW's (what timm's create_optimizer builds for --opt adamw and the reference
     # saves under checkpoint["optimizer"], /root/reference/tools/train.py:349-357), so checkpoints move both ways

@@ -73,6 +73,22 @@ class Shadow:
         if bf16_fresh:
             self.bound_generation = self.generation
 
+    def refresh_transposed(self):
+        """Re-cast every plain W^T copy handed out so far in ONE launch (FusedAdamW calls this after its update: the ~50 student
+        matrices are each far too small to fill the GPU as a launch of their own).  Copies requested for the first time, K-padded
+        ones and conv weights still go through ``get``."""
+        todo = [(k, v) for k, v in self._slots.items() if k[1] and not k[2] and not k[3] and len(v) > 2]
+        if not todo:
+            return
+        keys = tuple(k for k, _ in todo)
+        if getattr(self, "_t_keys", None) != keys or any(v[2].data_ptr() != v[0][2] for _, v in todo):
+            pairs = [(v[2].detach().reshape(v[2].shape[0], -1), v[1]) for _, v in todo]
+            self._t_table, self._t_keys = ops.cast_weight_table(pairs), keys
+        ops.cast_weight_group(self._t_table)
+        for k, v in todo:
+            p = v[2]
+            self._slots[k] = ((self.generation, p._version, p.data_ptr()), v[1], p)
+
     def get(self, p: torch.Tensor, transposed=False, pad_k_to=0, conv3x3=False):
         """conv3x3: p is a [out, cin, 3, 3] conv weight, served as [out, (ky, kx, cin)] to match ops.im2col3x3's K order."""
         key = (id(p), transposed, pad_k_to, conv3x3)
@@ -103,6 +119,8 @@ class Shadow:
             else:
                 buf = slot[1] if slot else torch.empty(cols, rows, device=p.device, dtype=BF16)
                 ops.cast_weight(w2, None, buf)
+                self._slots[key] = (stamp, buf, p)       # with the parameter: refresh_transposed() re-casts these in one launch
+                return buf
         self._slots[key] = (stamp, buf)
         return buf
 

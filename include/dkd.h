@@ -129,6 +129,14 @@ int dkd_scale_cast_bf16(const float* x, int32_t ldx, DkdRowMap xmap, const float
                         const void* add, int32_t add_is_f32, int32_t ldadd, void* y, int32_t ldy, int32_t M, int32_t D, void* stream);
 /* f32 -> bf16 flat cast; optionally also the transpose of a [rows, cols] matrix (w_t may be NULL). */
 int dkd_cast_weight(const float* w, void* w_bf16, void* w_t_bf16, int32_t rows, int32_t cols, void* stream);
+/* The transposed casts of a whole table of matrices in ONE launch.  `items` lives in DEVICE memory (the caller builds it once: the
+ * pointers of parameters and shadows are stable); first_tile = number of 32 x 32 tiles of all earlier items; total_tiles = the sum. */
+typedef struct DkdCastItem {
+  const float* w;      /* f32 [rows, cols] */
+  void* wt;            /* bf16 [cols, rows] */
+  int32_t rows, cols, first_tile, pad_;
+} DkdCastItem;
+int dkd_cast_weight_group(const DkdCastItem* items, int32_t n, int32_t total_tiles, void* stream);
 /* out[n] += sum_m x[amap(m), n]; x bf16 (or f32 if x_is_f32) [M, N] : bias gradients. */
 int dkd_colsum(const void* x, int32_t x_is_f32, int32_t ldx, DkdRowMap xmap, float* out, int32_t M, int32_t N, void* stream);
 /* y f32 [M, D] (+)= x (bf16 or f32) scattered through ymap rows (gradient of a token-strip view). */

@@ -16,8 +16,9 @@ reps = 20
 res = {}
 for name, M, N, K, epi in shapes:
     if only and name not in only: continue
-    a = torch.randn(M, K, device=dev).to(BF16)
-    b = (torch.randn(N, K, device=dev) * 0.05).to(BF16)
+    pad = int(os.environ.get("GB_PAD", "0"))      # extra elements per row of both operands (row stride K + pad): L2 channel spread
+    a = torch.randn(M, K + pad, device=dev).to(BF16)[:, :K]
+    b = (torch.randn(N, K + pad, device=dev) * 0.05).to(BF16)[:, :K]
     bias = torch.randn(N, device=dev)
     kw = dict(bias=bias)
     if epi == "gelu":

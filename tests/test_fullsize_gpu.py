@@ -192,3 +192,71 @@ def test_wide_gemm_ragged_rows(ops, epi):
         if epi == "gelu":
             ref = torch.nn.functional.gelu(ref)
         assert rel(out[lo:hi], ref) < 1e-2, (epi, lo)
+
+
+@pytest.mark.parametrize("kind", ["soft", "lrkd"])
+def test_real_architecture_step_matches_oracle(kind):
+    """The headline architectures themselves (DeiT-tiny / tiny-distilled students, DeiT-base-distilled / small-distilled teachers,
+    224 x 224, 1000 classes) at batch 4: loss and a spread of gradients against the CPU oracle (fp32 torch restatement of the
+    reference path), drop_path 0.  The golden fixtures use toy widths; this pins the 192 / 384 / 768-wide kernel paths."""
+    from oracle import loss_ref, vit_ref
+    from deltakd_amd import vit
+    from deltakd_amd.losses import DistillationLoss, call_base_loss
+    from deltakd_amd.models import attach_aux, forward_with_features
+    t_name = "deit_base_distilled_patch16_224" if kind == "lrkd" else "deit_small_distilled_patch16_224"
+    s_name = "deit_tiny_patch16_224" if kind == "lrkd" else "deit_tiny_distilled_patch16_224"
+    args = loss_ref.default_args(distillation_type=kind, dataset="imagenet-1k", lrkd_rank=64, alpha=0.1, tau=3.0, smoothing=0.1)
+    torch.manual_seed(3)
+    o_t = vit_ref.create_model_ref(t_name, 1000, 0.0).eval()
+    o_s = vit_ref.create_model_ref(s_name, 1000, 0.0).train()
+    loss_ref.attach_aux_ref(o_s, o_t, kind, 64)
+    with torch.no_grad():                                  # randomly initialised fc2 outputs are tiny: give the taps some scale
+        for net in (o_s, o_t):
+            for blk in net.blocks:
+                blk.mlp.fc2.weight.mul_(8.0)
+    for p in o_t.parameters():
+        p.requires_grad = False
+    g = torch.Generator().manual_seed(4)
+    x, y = torch.randn(4, 3, 224, 224, generator=g), torch.randint(0, 1000, (4,), generator=g)
+    ocrit = loss_ref.DistillationLossRef(loss_ref.call_base_loss_ref(args), o_t, kind, args.alpha, args.tau)
+    if kind == "lrkd":
+        out, feats = loss_ref.forward_with_features_ref(o_s, x)
+        with torch.no_grad():
+            _, tf = loss_ref.forward_with_features_ref(o_t, x)
+        targets = [loss_ref.lrkd_targets_ref(tf[i][:, 2:], 64) for i in (0, 1, 11)]
+        oloss = ocrit(x, out, o_s, feats, y, args, {"lrkd_targets": targets})
+    else:
+        oloss = ocrit(x, o_s(x), o_s, None, y, args, {})
+    oloss.backward()
+
+    t = vit.create_model(t_name, num_classes=1000, drop_path_rate=0.0)
+    s = vit.create_model(s_name, num_classes=1000, drop_path_rate=0.0)
+    attach_aux(s, t, kind, args)
+    if kind == "soft":
+        s.set_distilled_training(True)
+    t.load_state_dict(o_t.state_dict())
+    s.load_state_dict(o_s.state_dict())
+    t.to(DEV).eval()
+    s.to(DEV).train()
+    for p in t.parameters():
+        p.requires_grad = False
+    crit = DistillationLoss(call_base_loss(args), t, kind, args.alpha, args.tau)
+    if kind == "lrkd":
+        crit.injected["lrkd_targets"] = [tg.to(DEV) for tg in targets]     # the SVD's column signs are arbitrary: share the oracle's
+        hout, hfeats = forward_with_features(s, x.to(DEV))
+        hloss = crit(x.to(DEV), hout, s, hfeats, y.to(DEV), args)
+    else:
+        hloss = crit(x.to(DEV), s(x.to(DEV)), s, None, y.to(DEV), args)
+    hloss.backward()
+    assert abs(hloss.item() - oloss.item()) <= 1e-2 * abs(oloss.item()), (hloss.item(), oloss.item())
+    ref = dict(o_s.named_parameters())
+    checked = 0
+    for n, p in s.named_parameters():
+        if p.grad is None or ref[n].grad is None or ref[n].grad.abs().max() == 0:
+            continue
+        if any(k in n for k in ("blocks.0.", "blocks.5.", "blocks.11.", "patch_embed", "head", "align", "pos_embed", "cls_token")):
+            gr, go = p.grad.detach().cpu(), ref[n].grad
+            err = (gr - go).norm() / go.norm().clamp_min(1e-12)
+            assert err < 6e-2, (n, err.item())
+            checked += 1
+    assert checked >= 30

@@ -91,7 +91,7 @@ def cpu_baseline(cfg, batch=32, steps=3):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="lrkd", choices=sorted(CONFIGS))
     ap.add_argument("--batch", type=int, default=256, help="per-GPU batch")

@@ -93,3 +93,46 @@ extern "C" int dkd_block_bwd(const DkdBlock* bp, const DkdBlockGrads* gp, void* 
   TRY(dkd_layernorm_bwd(r.dT, 0, b.x, D, ID, b.ln1_w, b.mean1, b.rstd1, r.g, D, ID, 1, r.d_ln1_w, r.d_ln1_b, M, D, r.ln_ws, st));
   return DKD_OK;
 }
+
+// ---------------------------------------------------------------------------------------------- workspace queries
+namespace {
+inline int64_t al256(int64_t bytes) { return (bytes + 255) / 256 * 256; }
+}
+
+extern "C" int64_t dkd_layernorm_bwd_workspace_bytes(int32_t M, int32_t D) {
+  return al256((int64_t)2 * D * ((M + 63) / 64) * 4);
+}
+
+extern "C" int64_t dkd_block_fwd_workspace_bytes(int32_t B, int32_t N, int32_t D, int32_t H, int32_t hidden, int32_t training,
+                                                 int32_t with_tap, int64_t* bf16_bytes, int64_t* f32_bytes) {
+  const int64_t M = (int64_t)B * N;
+  int64_t b16, f32 = 0;
+  if (training) {
+    b16 = al256(M * D * 2) * 3 + al256(M * 3 * D * 2) + al256(M * hidden * 2) * 2 + (with_tap ? al256(M * D * 2) : 0);
+    f32 = al256(M * D * 4) * 2 + al256(M * 4) * 4 + al256((int64_t)B * H * N * 4);
+  } else {
+    b16 = al256(M * D * 2) * 2 + al256(M * 3 * D * 2) + al256(M * hidden * 2);
+  }
+  if (bf16_bytes) *bf16_bytes = b16;
+  if (f32_bytes) *f32_bytes = f32;
+  return b16 + f32;
+}
+
+extern "C" int64_t dkd_block_bwd_workspace_bytes(int32_t B, int32_t N, int32_t D, int32_t hidden) {
+  const int64_t M = (int64_t)B * N;
+  return al256(M * D * 2) * 3 + al256(M * hidden * 2) + al256(M * 3 * D * 2) + dkd_layernorm_bwd_workspace_bytes((int32_t)M, D);
+}
+
+extern "C" int dkd_block_bwd_workspace_carve(void* ws, int32_t B, int32_t N, int32_t D, int32_t hidden, DkdBlockGrads* gr) {
+  DKD_CHECK_ARG(ws && gr && B > 0 && N > 0 && D > 0 && hidden > 0, "block_bwd_workspace_carve: bad arguments");
+  DKD_CHECK_ARG(((uintptr_t)ws & 255) == 0, "block_bwd_workspace_carve: the workspace must be 256-byte aligned");
+  const int64_t M = (int64_t)B * N;
+  char* p = (char*)ws;
+  gr->dF = p;      p += al256(M * D * 2);
+  gr->dT = p;      p += al256(M * D * 2);
+  gr->dH = p;      p += al256(M * hidden * 2);
+  gr->dqkv = p;    p += al256(M * 3 * D * 2);
+  gr->ln_ws = (float*)p;  p += dkd_layernorm_bwd_workspace_bytes((int32_t)M, D);
+  gr->dF2 = p;
+  return DKD_OK;
+}

@@ -71,7 +71,17 @@ class DataParallel(nn.Module):
         depth = len(blocks)
         for lo in range(0, depth, blocks_per_bucket):
             params = [p for b in list(blocks)[lo:lo + blocks_per_bucket] for p in b.parameters() if p.requires_grad]
-            plan[lo] = self._opt.grad_ranges(params)
+            rng = self._opt.grad_ranges(params)
+            # the "smallest contiguous range" must hold these blocks' parameters and nothing else: a foreign parameter inside it
+            # (e.g. an aux module registered between blocks) would be reduced before its gradient is final and then skipped by the
+            # tail sync.  If that ever happens, leave the bucket to the tail sync.
+            covered = {}
+            for p in params:
+                for i, (s, e) in self._opt.grad_ranges([p]).items():
+                    covered[i] = covered.get(i, 0) + (e - s)
+            if any(covered.get(i, 0) != e - s for i, (s, e) in rng.items()):
+                continue
+            plan[lo] = rng
         return plan
 
     def _on_block_backward(self, idx):

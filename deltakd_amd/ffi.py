@@ -117,6 +117,11 @@ _SIGS = {
     "dkd_probe_end": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int32)]),
     "dkd_blocks_fwd": (C.c_int, [C.POINTER(Block), C.c_int32, C.c_void_p]),
     "dkd_block_bwd": (C.c_int, [C.POINTER(Block), C.POINTER(BlockGrads), C.c_void_p]),
+    "dkd_layernorm_bwd_workspace_bytes": (C.c_int64, [C.c_int32, C.c_int32]),
+    "dkd_block_fwd_workspace_bytes": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                                  C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "dkd_block_bwd_workspace_bytes": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+    "dkd_block_bwd_workspace_carve": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(BlockGrads)]),
     "dkd_jacobi_eigh": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "dkd_adamw_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float,
                                  C.c_float, C.c_float, C.c_float, C.c_int32, C.c_float, C.c_void_p]),

@@ -48,7 +48,7 @@ class _MgdFn(torch.autograd.Function):
         tap2, cols1, y1, cols2, dy2, mask = ctx.saved
         B, N, Ds, npre, hw, M, Dt = ctx.dims
         c1, c2 = sm.generation[0], sm.generation[2]
-        dy2.mul_(g.to(BF16))
+        dy2.mul_(g)
 
         def conv_wgrad(dy, cols, conv):
             dwp = torch.zeros(Dt, 9 * Dt, device=dy.device, dtype=F32)
@@ -134,7 +134,7 @@ class _DenoiseFn(torch.autograd.Function):
         x_in, pre, h, dpred = ctx.saved
         B, P, Dt = ctx.dims
         f0, f2 = dn.net[0], dn.net[2]
-        dpred.mul_(g.to(BF16))
+        dpred.mul_(g)
         ops.gemm_tn(dpred, h, ensure_grad(f2.weight), colsum=ensure_grad(f2.bias))
         dh = ops.gemm_nt(dpred, sh.get(f2.weight, transposed=True), dgelu=True, preact=pre)
         ops.gemm_tn(dh, x_in, ensure_grad(f0.weight), colsum=ensure_grad(f0.bias))
@@ -144,8 +144,9 @@ class _DenoiseFn(torch.autograd.Function):
         return dtemb, None, None, None, None, None, None, None, None
 
 
-def diffkd_loss(student_model, student_features, teacher_features, alpha, npre_s, npre_t, injected=None):
-    """alpha * (5e-5 / 3) * sum_i [mse(pred_noise_i, noise_i) + mean(w_t) * mse(s^_i, t^_i)]   (model/loss.py:105-155)."""
+def diffkd_loss(student_model, student_features, teacher_features, alpha, npre_s, npre_t, injected=None, terms_out=None):
+    """alpha * (5e-5 / 3) * sum_i [mse(pred_noise_i, noise_i) + mean(w_t) * mse(s^_i, t^_i)]   (model/loss.py:105-155).
+    ``terms_out`` (list, optional) receives the six addends (denoise_i, match_i) as detached device scalars."""
     injected = injected or {}
     sm = student_model
     sel_s = [student_features[0], student_features[1], student_features[-1]]
@@ -176,6 +177,8 @@ def diffkd_loss(student_model, student_features, teacher_features, alpha, npre_s
         def cb(s, loss, Kp, t_hat=t_hat, M=M, Dt=Dt):
             return ops.normalize_mse(s, t_hat, loss, scale / (M * Dt), w_scalar=w_mean, ld_grad=Kp)
         term_match = _AlignTermFn.apply(sel_s[i], sm.align[i], sm._shadow, npre_s, cb)
+        if terms_out is not None:
+            terms_out += [term_dn.detach(), term_match.detach()]
         total = term_dn + term_match if total is None else total + term_dn + term_match
     return total
 

@@ -43,10 +43,11 @@ class FusedAdamW(torch.optim.Optimizer):
         self._where = {}               # id(param) -> (flat index, start, end) inside the flat buffers
         self._step = 0
         self.grad_sync = None          # set by deltakd_amd.ddp: called with the flat grad buffers before the update
+        self._synced = False           # gradients of the current iteration already averaged (sync_grads() ran ahead of step())
         self._flatten()
 
     def _flatten(self):
-        bound = {}
+        bound, bound_params = {}, []
         for group in self.param_groups:
             ps = [p for p in group["params"] if p.requires_grad]
             if not ps:
@@ -70,12 +71,13 @@ class FusedAdamW(torch.optim.Optimizer):
                 if old_grad is not None:
                     p.grad.copy_(old_grad)
                 bound[id(p)] = fb[off:off + k]
+                bound_params.append(p)
                 self._where[id(p)] = (len(self._flat), off, off + n)
                 off += n
             fb.copy_(fp)
             self._flat.append(dict(p=fp, g=fg, bf=fb, m=torch.zeros_like(fp), v=torch.zeros_like(fp)))
         for sh in self._shadows:
-            sh.bind_flat(bound)
+            sh.bind_flat(bound, bound_params)
             sh.optimizer_stepped(bf16_fresh=True)
 
     def grad_ranges(self, params):
@@ -98,13 +100,39 @@ class FusedAdamW(torch.optim.Optimizer):
         for f in self._flat:
             if f is not None:
                 f["g"].zero_()
+        self._synced = False
+
+    @torch.no_grad()
+    def sync_grads(self):
+        """Data parallel: finish the gradient averaging of this iteration NOW (the tail all-reduce and the join of the comm stream,
+        deltakd_amd.ddp).  Anything that reads the averaged gradients before ``step()`` -- gradient clipping -- calls this first, as
+        torch DDP has finished its all-reduce by the time ``backward()`` returns (tools/engine.py:61-62 of the reference clips inside
+        the scaler, after backward).  Idempotent per iteration; ``step()`` calls it if nobody did."""
+        if self.grad_sync is not None and not self._synced:
+            self.grad_sync(self.flat_grads)
+        self._synced = True
+
+    @torch.no_grad()
+    def clip_grad_norm_(self, max_norm, norm_type=2.0):
+        """torch.nn.utils.clip_grad_norm_ over the flat gradient buffers (one norm per buffer instead of one per parameter);
+        -> total norm (0-dim device tensor).  Averages the gradients first when data parallel."""
+        self.sync_grads()
+        flats = self.flat_grads
+        if norm_type == float("inf"):
+            total = torch.stack([g.abs().max() for g in flats]).max()
+        else:
+            total = torch.stack([torch.linalg.vector_norm(g, norm_type) for g in flats]).norm(norm_type)
+        coef = (max_norm / (total + 1e-6)).clamp(max=1.0)
+        for g in flats:
+            g.mul_(coef)
+        return total
 
     @torch.no_grad()
     def step(self, closure=None):
         if closure is not None:
             raise NotImplementedError("FusedAdamW does not take a closure")
-        if self.grad_sync is not None:
-            self.grad_sync(self.flat_grads)
+        self.sync_grads()
+        self._synced = False
         self._step += 1
         for group, f in zip(self.param_groups, self._flat):
             if f is None:

@@ -26,7 +26,18 @@ class NativeScaler:
         if need_update:
             if clip_grad is not None:
                 assert parameters is not None
-                torch.nn.utils.clip_grad_norm_([p for p in parameters if p.grad is not None], clip_grad)
+                # data parallel: the norm must be taken over the AVERAGED gradients (torch DDP has finished its all-reduce when
+                # backward returns); deltakd_amd.ddp finishes its tail all-reduce in sync_grads()
+                if clip_mode == "norm" and hasattr(optimizer, "clip_grad_norm_"):
+                    optimizer.clip_grad_norm_(clip_grad)                 # flat buffers: syncs first, one norm per buffer
+                else:
+                    if hasattr(optimizer, "sync_grads"):
+                        optimizer.sync_grads()
+                    params = [p for p in parameters if p.grad is not None]
+                    if clip_mode == "value":
+                        torch.nn.utils.clip_grad_value_(params, clip_grad)
+                    else:
+                        torch.nn.utils.clip_grad_norm_(params, clip_grad)
             optimizer.step()
 
     # checkpoint["scaler"]: timm's NativeScaler saves its torch GradScaler's state; this one scales nothing, so it writes a disabled
@@ -122,6 +133,11 @@ class ModelEma:
         self.ema = copy.deepcopy(inner).eval()
         for p in self.ema.parameters():
             p.requires_grad_(False)
+        self._shadows = []
+        for m in self.ema.modules():              # the copy must not share (or trust) the student's bf16 weight shadows
+            if hasattr(m, "_shadow"):
+                m._shadow = type(m._shadow)()
+                self._shadows.append(m._shadow)
         self._flat = None
         flats = getattr(optimizer, "_flat", None)
         if flats:
@@ -145,6 +161,8 @@ class ModelEma:
             for pair in self._flat:
                 if pair is not None:
                     ops.ema_update(pair[1], pair[0], self.decay)
+            for sh in self._shadows:               # raw kernel wrote the masters: their bf16 copies are stale
+                sh.optimizer_stepped(bf16_fresh=False)
             return
         inner = model.module if hasattr(model, "module") else model
         for (k, ev), (_, mv) in zip(self.ema.state_dict().items(), inner.state_dict().items()):

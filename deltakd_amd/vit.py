@@ -61,17 +61,23 @@ class Shadow:
     def __init__(self):
         self._slots = {}
         self._bound = {}          # id(param) -> bf16 view kept fresh by FusedAdamW
+        self._params = {}         # id(param) -> param, for the bound ones
+        self._fresh_versions = {} # id(param) -> p._version when the AdamW kernel last refreshed the bound view
         self.generation = 0
         self.bound_generation = -1
 
-    def bind_flat(self, views):
+    def bind_flat(self, views, params=()):
         self._bound = dict(views)
+        self._params = {id(p): p for p in params}
         self._slots.clear()
 
     def optimizer_stepped(self, bf16_fresh: bool):
+        """The masters changed behind torch's back (raw kernel).  bf16_fresh: the same kernel re-cast the bound bf16 views; they
+        are trusted only while the master's torch version stays what it is now (load_state_dict / in-place edits bump it)."""
         self.generation += 1
         if bf16_fresh:
             self.bound_generation = self.generation
+            self._fresh_versions = {i: p._version for i, p in self._params.items()}
 
     def refresh_transposed(self):
         """Re-cast every plain W^T copy handed out so far in ONE launch (FusedAdamW calls this after its update: the ~50 student
@@ -103,7 +109,8 @@ class Shadow:
         rows, cols = w2.shape
         if not transposed:
             bound = None if conv3x3 else self._bound.get(id(p))
-            if bound is not None and self.bound_generation == self.generation:
+            if (bound is not None and self.bound_generation == self.generation
+                    and self._fresh_versions.get(id(p), p._version) == p._version):
                 buf = bound.view(rows, cols)                      # already refreshed by the AdamW kernel
             else:
                 buf = slot[1] if slot else (bound.view(rows, cols) if bound is not None else
@@ -127,11 +134,72 @@ class Shadow:
     def clear(self):
         self._slots.clear()
         self._bound = {}
+        self._params = {}
+        self._fresh_versions = {}
 
 
 # ----------------------------------------------------------------------------------------------- parameter holders
+def _pad64(n):
+    return (n + 63) // 64 * 64
+
+
+class _LinearFn(torch.autograd.Function):
+    """y = x W^T + b on the MFMA GEMMs, for callers that use an aux Linear the way the reference does
+    (``student_model.align[i](feat[:, 1:])``, model/loss.py:88-92,190,426).  x: any float dtype / strides, [..., in] -> f32 [..., out].
+    The fused loss terms (deltakd_amd.losses._AlignTermFn) do not come through here: they read the tap through a row map and keep
+    the bf16 shadows; this is the compatible path, with per-call casts of the weight."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        K, N = weight.shape[1], weight.shape[0]
+        lead = x.shape[:-1]
+        Kp, Np = _pad64(K), _pad64(N)
+        x2 = x.reshape(-1, K)
+        M = x2.shape[0]
+        if Kp == K:
+            xb = x2.to(BF16).contiguous()
+        else:
+            xb = torch.zeros(M, Kp, device=x.device, dtype=BF16)
+            xb[:, :K] = x2
+        w = weight.detach().contiguous()
+        wb = torch.empty(N, K, device=x.device, dtype=BF16)
+        wt = torch.empty(K, N, device=x.device, dtype=BF16)
+        ops.cast_weight(w, wb, wt)
+        if Kp != K:
+            wp = torch.zeros(N, Kp, device=x.device, dtype=BF16)
+            wp[:, :K] = wb
+            wb = wp
+        if Np != N:                                      # dgrad contracts over out_features: K-pad W^T
+            wtp = torch.zeros(K, Np, device=x.device, dtype=BF16)
+            wtp[:, :N] = wt
+            wt = wtp
+        out = ops.gemm_nt(xb, wb, bias=None if bias is None else bias.detach(), out_f32=True)
+        ctx.saved = (xb, wt)
+        ctx.dims = (lead, M, K, N, Kp, Np, x.dtype, bias is not None)
+        return out.view(*lead, N)
+
+    @staticmethod
+    def backward(ctx, g):
+        xb, wt = ctx.saved
+        lead, M, K, N, Kp, Np, xdtype, has_bias = ctx.dims
+        g2 = g.reshape(M, N)
+        if Np == N:
+            gb = g2.to(BF16).contiguous()
+        else:
+            gb = torch.zeros(M, Np, device=g.device, dtype=BF16)
+            gb[:, :N] = g2
+        dw = torch.zeros(N, Kp, device=g.device, dtype=F32)
+        db = torch.zeros(N, device=g.device, dtype=F32) if has_bias else None
+        ops.gemm_tn(gb, xb, dw, N1=N, colsum=db)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = ops.gemm_nt(gb, wt, out_f32=True).view(*lead, K).to(xdtype)
+        ctx.saved = None
+        return dx, dw[:, :K], db
+
+
 class Linear(nn.Module):
-    """Parameter holder with nn.Linear's layout (weight [out, in], bias [out]); callable on bf16 token matrices."""
+    """nn.Linear's layout (weight [out, in], bias [out]) and call contract, computed by libdkd's GEMMs (no torch matmul)."""
 
     def __init__(self, in_features, out_features, bias=True):
         super().__init__()
@@ -139,6 +207,9 @@ class Linear(nn.Module):
         self.weight = nn.Parameter(torch.empty(out_features, in_features))
         self.bias = nn.Parameter(torch.zeros(out_features)) if bias else None
         _trunc_normal_(self.weight, std=.02)
+
+    def forward(self, x):
+        return _LinearFn.apply(x, self.weight, self.bias)
 
     def extra_repr(self):
         return f"{self.in_features}, {self.out_features}"
@@ -249,9 +320,10 @@ def _block_forward_train(x, B, N, blk: Block, sh: Shadow, s1, s2, want_tap: bool
     return x2, tap, (bs, slab16, slab32, x, s1, s2)
 
 
-def _backward_workspace(model, M, D, Hd, dev):
+def _backward_workspace(model, bs, dev):
+    """The scratch of dkd_block_bwd, shared by all blocks of a model (size from the library: dkd_block_bwd_workspace_bytes)."""
     ws = getattr(model, "_bwd_ws", None)
-    need = _bytes_al(M * D, 2) * 3 + _bytes_al(M * Hd, 2) + _bytes_al(M * 3 * D, 2) + _bytes_al(2 * D * ((M + 63) // 64), 4)
+    need = ffi.lib().dkd_block_bwd_workspace_bytes(bs.B, bs.N, bs.D, bs.hidden)
     if ws is None or ws.numel() < need or ws.device != dev:
         ws = torch.empty(need, device=dev, dtype=torch.uint8)
         model._bwd_ws = ws
@@ -261,18 +333,11 @@ def _backward_workspace(model, M, D, Hd, dev):
 def _block_backward(g, gtap, model, blk: Block, saved):
     """g: f32 [M, D] gradient w.r.t. the block output (overwritten with the input gradient and returned)."""
     bs, slab16, slab32, x, s1, s2 = saved
-    M, D, Hd = bs.B * bs.N, bs.D, bs.hidden
     _fill_weights(bs, blk, model._shadow, bs.B, bs.N, backward=True)
-    ws = _backward_workspace(model, M, D, Hd, g.device)
-    p = ws.data_ptr()
+    ws = _backward_workspace(model, bs, g.device)
     gr = ffi.BlockGrads()
+    ffi.check(ffi.lib().dkd_block_bwd_workspace_carve(ws.data_ptr(), bs.B, bs.N, bs.D, bs.hidden, ffi.C.byref(gr)), "bwd_workspace")
     gr.g, gr.gtap = g.data_ptr(), ffi.ptr(gtap)
-    gr.dF = p
-    gr.dT = p + _bytes_al(M * D, 2)
-    gr.dH = gr.dT + _bytes_al(M * D, 2)
-    gr.dqkv = gr.dH + _bytes_al(M * Hd, 2)
-    gr.ln_ws = gr.dqkv + _bytes_al(M * 3 * D, 2)       # LayerNorm backward: per-block partial sums (no same-address atomics)
-    gr.dF2 = gr.ln_ws + _bytes_al(2 * D * ((M + 63) // 64), 4)   # keeps the MLP branch's dF alive: one launch for all 4 wgrads
     a, m = blk.attn, blk.mlp
     gr.d_ln1_w, gr.d_ln1_b = ensure_grad(blk.norm1.weight).data_ptr(), ensure_grad(blk.norm1.bias).data_ptr()
     gr.d_ln2_w, gr.d_ln2_b = ensure_grad(blk.norm2.weight).data_ptr(), ensure_grad(blk.norm2.bias).data_ptr()
@@ -442,7 +507,9 @@ class VisionTransformer(nn.Module):
         if distilled:
             _trunc_normal_(self.dist_token, std=.02)
         self._shadow = Shadow()
-        self._keep: Optional[List[torch.Tensor]] = None
+        self._keep = None
+        # weights loaded into the fp32 masters (resume / finetune / eval-only use) must reach the bf16 copies the GEMMs read
+        self.register_load_state_dict_post_hook(lambda module, incompatible: module._shadow.optimizer_stepped(bf16_fresh=False))
 
     # -- timm surface
     def no_weight_decay(self):
@@ -451,9 +518,13 @@ class VisionTransformer(nn.Module):
     def set_distilled_training(self, enable=True):
         self.distilled_training = enable
 
-    def set_droppath_keep(self, keep: Optional[Sequence[torch.Tensor]]):
-        """Inject the Bernoulli draws of DropPath (2 per block, [B] 0/1) instead of sampling them (parity tests)."""
-        self._keep = None if keep is None else [k.to(F32) for k in keep]
+    def set_droppath_keep(self, keep):
+        """Inject the Bernoulli draws of DropPath (2 per block, [B] 0/1) instead of sampling them (parity tests).  ``keep``: a list used
+        by every training forward, or an iterator yielding one such list per training forward (multi-step tests)."""
+        if keep is None or hasattr(keep, "__next__"):
+            self._keep = keep
+        else:
+            self._keep = [k.to(F32) for k in keep]
 
     def _apply(self, fn, *a, **k):
         self._shadow.clear()
@@ -465,7 +536,8 @@ class VisionTransformer(nn.Module):
             return [None] * (2 * len(self.blocks))
         probs = [blk.drop_prob for blk in self.blocks for _ in range(2)]
         if self._keep is not None:
-            return [None if p == 0.0 else (self._keep[i].to(device) / (1.0 - p)).contiguous() for i, p in enumerate(probs)]
+            keep = next(self._keep) if hasattr(self._keep, "__next__") else self._keep
+            return [None if p == 0.0 else (keep[i].to(device=device, dtype=F32) / (1.0 - p)).contiguous() for i, p in enumerate(probs)]
         if max(probs) == 0.0:
             return [None] * len(probs)
         keep_prob = 1.0 - torch.tensor(probs, device=device, dtype=F32)[:, None]

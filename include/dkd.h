@@ -12,7 +12,10 @@
  *   - all launches are asynchronous on `stream` (a hipStream_t passed as void*; NULL = default stream).
  *   - return 0 on success, <0 on error; dkd_last_error() returns a thread-local message.
  *   - bf16 tensors are raw uint16_t payloads; "f32" = float.
- *   - no global mutable state: safe to call from torch's main and autograd threads concurrently.
+ *   - global state is limited to write-once caches of device properties (CU count, a kernel attribute set on first use) and the
+ *     launch probe of bench.py (mutex-protected, off by default); nothing else is shared between calls, so the entry points are
+ *     safe to call from torch's main and autograd threads concurrently.  One process drives one GPU.
+ *   - scratch memory is always passed in by the caller; the dkd_*_workspace_bytes() queries say how much.
  */
 #ifndef DKD_H
 #define DKD_H
@@ -227,6 +230,19 @@ typedef struct {
 
 int dkd_blocks_fwd(const DkdBlock* blocks, int32_t n_blocks, void* stream);
 int dkd_block_bwd(const DkdBlock* blk, const DkdBlockGrads* gr, void* stream);
+
+/* Workspace queries (bytes; every sub-buffer starts on a 256-byte boundary).
+ * dkd_layernorm_bwd_workspace_bytes: the `ws` scratch of dkd_layernorm_bwd.
+ * dkd_block_fwd_workspace_bytes: the activation slabs of one block of dkd_blocks_fwd -- *bf16_bytes: y1 | qkv | o | y2 | pre | h [| tap]
+ *   (training) or y | qkv | o | h (inference, shared by all blocks); *f32_bytes: x1 | x2 | mean1 | rstd1 | mean2 | rstd2 | lse (training)
+ *   or 0.  Returns their sum.
+ * dkd_block_bwd_workspace_bytes: the scratch of dkd_block_bwd (dF | dT | dH | dqkv | ln_ws | dF2), shared by all blocks;
+ * dkd_block_bwd_workspace_carve fills those six pointers of `gr` from a buffer of that size. */
+int64_t dkd_layernorm_bwd_workspace_bytes(int32_t M, int32_t D);
+int64_t dkd_block_fwd_workspace_bytes(int32_t B, int32_t N, int32_t D, int32_t H, int32_t hidden, int32_t training, int32_t with_tap,
+                                      int64_t* bf16_bytes, int64_t* f32_bytes);
+int64_t dkd_block_bwd_workspace_bytes(int32_t B, int32_t N, int32_t D, int32_t hidden);
+int dkd_block_bwd_workspace_carve(void* ws, int32_t B, int32_t N, int32_t D, int32_t hidden, DkdBlockGrads* gr);
 
 /* ---------------------------------------------------------------- small dense eigensolver (LRKD target, model/loss.py:321) */
 /* Batched cyclic Jacobi: A f32 [batch, n, n] symmetric, n <= 128 -> evals [batch, n] (unsorted), evecs [batch, n, n]

@@ -230,8 +230,85 @@ def main():
             tol = 2e-3 if kind == "lrkd" else 1e-5   # lrkd: fresh SVD inside the reference vs stored targets
             assert rel < tol and gmax < max(tol, 1e-4), (name, report[name])
 
+            # --- the two addends of the loss, each computed by the reference's own code WITHOUT forming total - base in fp32 (the
+            # distillation term is 1e-6 of the loss for some branches): loss = w_b * base + w_d * d
+            #   base : the reference's base criterion on the reference student's logits;
+            #   d    : alpha-weighted branches (soft, hard, lrkd, diffkd: model/loss.py:241) -> the reference's DistillationLoss built
+            #          with alpha = 1 (base * 0 + d * 1); free-function branches (mgd, vitkd, curkd, saliency_mgd) -> that function;
+            #          wasskd (inline, base + 5 d, d ~ 0.3 of the loss) -> total - base.
+            # Same seed (99) before every call, so every call consumes the draws of the main run.
+            def grads_or_zero():
+                return {"grad." + k: (p.grad.detach().cpu().numpy().copy() if p.grad is not None else np.zeros(tuple(p.shape), np.float32))
+                        for k, p in student.named_parameters()}
+
+            out_b, feats_b = run_student()
+            logits_b = out_b if isinstance(out_b, torch.Tensor) else out_b[0]
+            base = crit.base_criterion(logits_b, tgt)
+            student.zero_grad()
+            base.backward()
+            g_base = grads_or_zero()
+            alpha_weighted = kind in ("soft", "hard", "lrkd", "diffkd")
+            w_b = (1.0 - args.alpha) if alpha_weighted else 1.0
+            d_val, g_d, w_d = 0.0, None, 0.0
+            if alpha_weighted:
+                crit1 = ref_loss.DistillationLoss(ref_loss.call_base_loss(args), teacher, kind, 1.0, args.tau)
+                out_d, feats_d = run_student()
+                torch.manual_seed(99)
+                d = crit1(x, out_d, student, feats_d, tgt, args)
+                w_d = args.alpha
+            elif kind in ("mgd", "vitkd", "curkd", "saliency_mgd"):
+                out_d, feats_d = run_student()
+                with torch.no_grad():
+                    _, tf_ref = ref_models.forward_with_features(teacher, x)
+                torch.manual_seed(99)
+                if kind == "mgd":
+                    d = ref_loss.mgd_loss(student, feats_d, tf_ref, args)
+                elif kind == "vitkd":
+                    d = ref_loss.vitkd_loss(student, feats_d, tf_ref, alpha_vitkd=0.00003, beta_vitkd=0.000003, lambda_vitkd=0.5)
+                elif kind == "curkd":
+                    d = ref_loss.curkd_loss(student, feats_d, tf_ref, args)
+                else:
+                    d = ref_loss.saliency_mgd_loss(student, feats_d, tf_ref, args)
+                w_d = 1.0
+            else:
+                d = None
+            if d is not None:
+                student.zero_grad()
+                d.backward()
+                g_d = grads_or_zero()
+                d_val = float(d.item())
+            elif kind == "wasskd":
+                w_d = 5.0
+                d_val = (float(loss.item()) - float(base.item())) / 5.0
+                g_d = {k: (ref_grads.get(k, np.zeros_like(g_base[k])) - g_base[k]) / 5.0 for k in g_base}
+            base_term, distill_term = w_b * float(base.item()), w_d * d_val
+            assert abs(loss.item() - (base_term + distill_term)) <= 2e-6 * abs(loss.item()), (name, loss.item(), base_term, distill_term)
+            if g_d is not None:
+                for k in ref_grads:
+                    comp = w_b * g_base[k] + w_d * g_d[k]
+                    den = np.abs(ref_grads[k]).max() + 1e-12
+                    assert np.abs(comp - ref_grads[k]).max() / den < 1e-4, (name, k)
+            report[name].update(base_term=base_term, distill_term=distill_term)
+            # --- "strong" variant: the same reference quantities recombined with the distillation term scaled by K so that it is
+            # half of the base term (the reference's constants leave it at 1e-6 .. 1e-2 of the loss at toy size, where a loss-level
+            # tolerance cannot see it):  loss_K = w_b base + K w_d d,  grad_K = w_b grad(base) + K w_d grad(d).
+            strong = {}
+            if g_d is not None and 0.0 < distill_term < 0.05 * base_term:
+                K = float(f"{0.5 * base_term / distill_term:.2g}")
+                strong["strong.scale"] = np.array(K, dtype=np.float64)
+                strong["strong.loss"] = np.array(base_term + K * distill_term, dtype=np.float64)
+                s_names = sorted(ref_grads)
+                sg = {k: (w_b * g_base[k].astype(np.float64) + K * w_d * g_d[k].astype(np.float64)) for k in s_names}
+                strong["strong.grad_norms"] = np.array([np.sqrt((sg[k] ** 2).sum()) for k in s_names])
+                for k in s_names:
+                    short = k[len("grad."):]
+                    if not short.startswith("blocks.") or short.split(".")[1] in ("0", "5", "11"):
+                        strong["strong." + k] = sg[k].astype(np.float32)
+                report[name].update(strong_scale=K)
+
             logits = out if isinstance(out, torch.Tensor) else out[0]
             fx = dict(x=x.numpy(), labels=labels.numpy(), soft_targets=soft_targets.numpy(),
+                      base_loss=np.array(base_term, dtype=np.float64), distill_loss=np.array(distill_term, dtype=np.float64),
                       use_soft_label=np.array(int(soft_label)), loss=np.array(loss.item(), dtype=np.float64),
                       student_logits=logits.detach().numpy(), teacher_logits=t_logits.numpy(),
                       keep=np.stack([k.numpy() for k in keep]).astype(np.uint8),
@@ -244,6 +321,7 @@ def main():
                     fx[f"student_feat{i}"] = feats[i].detach().numpy()
                     fx[f"teacher_feat{i}"] = t_feats[i].numpy()
             fx.update(draws_np)
+            fx.update(strong)
             fx.update(sd_np(student, "student."))
             if not teacher_saved:     # identical in every fixture (own seed): stored once
                 np.savez_compressed(os.path.join(OUT, "toy_teacher.npz"), **sd_np(teacher, "teacher."))

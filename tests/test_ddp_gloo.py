@@ -42,6 +42,21 @@ class RangedOpt(FlatOpt):
         return {0: (min(offs), max(offs) + 64)} if offs else {}
 
 
+class ClipOpt(FlatOpt):
+    """FlatOpt + the REAL FusedAdamW.sync_grads / clip_grad_norm_ (they only touch grad_sync, _synced and flat_grads)"""
+    _synced = False
+
+    def step(self):
+        self.sync_grads()
+        self._synced = False
+
+
+def _bind_fused_methods():
+    from deltakd_amd.optim import FusedAdamW
+    ClipOpt.sync_grads = FusedAdamW.sync_grads
+    ClipOpt.clip_grad_norm_ = FusedAdamW.clip_grad_norm_
+
+
 class Blocky(nn.Module):
     def __init__(self):
         super().__init__()
@@ -75,7 +90,19 @@ def _worker(rank, world, port, q):
     partial = opt2.flat.clone()                   # block ranges are reduced, the 4 trailing segments are not yet
     opt2.step()
     overlap = (partial.tolist(), opt2.flat.tolist())
+    # clipping under data parallel: NativeScaler must average the gradients BEFORE it takes the norm, so that
+    # every rank scales by the same factor: result == clip(mean(g)), identical on both ranks
+    from deltakd_amd.shims import NativeScaler
+    _bind_fused_methods()
+    net3 = nn.Linear(2, 2)
+    opt3 = ClipOpt(300)
+    DataParallel(net3, opt3, bucket_bytes=256)
+    opt3.flat.copy_(torch.linspace(-1, 1, 300) * (3.0 if rank == 0 else 1.0))       # rank-dependent gradients, mean = 2 x linspace
+    dummy = (net3.weight * 0).sum()
+    NativeScaler()(dummy, opt3, clip_grad=0.5, parameters=net3.parameters())
+    clipped = opt3.flat.tolist()
     gathered = [None] * world
+    overlap = overlap + (clipped,)
     as_lists = lambda ts: [t.tolist() for t in ts]      # plain lists: no shared-memory handles through the queue
     dist.all_gather_object(gathered, (as_lists(w0), as_lists(local), as_lists(synced), opt.flat.tolist(), overlap))
     if rank == 0:
@@ -107,3 +134,7 @@ def test_two_rank_gradient_averaging():
     for ga, gb, xa, xb in zip(la, lb, sa, sb):
         assert torch.allclose(T(xa), (T(ga) + T(gb)) / 2) and torch.equal(T(xa), T(xb))
     assert torch.allclose(T(fa), torch.arange(1000.) * 1.5) and fa == fb
+    mean = torch.linspace(-1, 1, 300) * 2.0
+    want_clip = mean * (0.5 / (mean.norm() + 1e-6))
+    assert ova[2] == ovb[2], "ranks hold different gradients after clipping"
+    assert torch.allclose(T(ova[2]), want_clip, atol=1e-6)

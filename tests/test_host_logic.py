@@ -165,7 +165,7 @@ def test_c_abi_library_exports_every_declared_symbol():
     """The shared library loads without a GPU and exports exactly the entry points include/dkd.h declares."""
     from deltakd_amd import ffi
     header = open(os.path.join(ROOT, "include", "dkd.h")).read()
-    declared = set(re.findall(r"^(?:int|const char\*)\s+(dkd_\w+)\s*\(", header, re.M))
+    declared = set(re.findall(r"^(?:int|int64_t|const char\*)\s+(dkd_\w+)\s*\(", header, re.M))
     assert declared, "no declarations parsed"
     handle = ffi.lib()
     for name in declared:
@@ -175,6 +175,20 @@ def test_c_abi_library_exports_every_declared_symbol():
     # argument errors come back through the error channel, not as crashes (no kernel is launched for a bad call)
     rc = handle.dkd_gemm_nt(None, None)
     assert rc == -1 and b"null" in handle.dkd_last_error()
+    # workspace queries are host arithmetic: the headline student block, B = 256, N = 197, D = 192, hidden 768
+    M, D, Hd = 256 * 197, 192, 768
+    al = lambda n: (n + 255) // 256 * 256
+    assert handle.dkd_layernorm_bwd_workspace_bytes(M, D) == al(2 * D * ((M + 63) // 64) * 4)
+    assert handle.dkd_block_bwd_workspace_bytes(256, 197, D, Hd) == (3 * al(M * D * 2) + al(M * Hd * 2) + al(M * 3 * D * 2)
+                                                                      + handle.dkd_layernorm_bwd_workspace_bytes(M, D))
+    b16, f32 = ffi.C.c_int64(), ffi.C.c_int64()
+    tot = handle.dkd_block_fwd_workspace_bytes(256, 197, D, 3, Hd, 1, 1, ffi.C.byref(b16), ffi.C.byref(f32))
+    assert tot == b16.value + f32.value and b16.value == 4 * al(M * D * 2) + al(M * 3 * D * 2) + 2 * al(M * Hd * 2)
+    assert f32.value == 2 * al(M * D * 4) + 4 * al(M * 4) + al(256 * 3 * 197 * 4)
+    gr = ffi.BlockGrads()
+    assert handle.dkd_block_bwd_workspace_carve(0x10000, 256, 197, D, Hd, ffi.C.byref(gr)) == 0      # pointer arithmetic only
+    assert gr.dF == 0x10000 and gr.dT == gr.dF + al(M * D * 2) and gr.dF2 + al(M * D * 2) - 0x10000 == \
+        handle.dkd_block_bwd_workspace_bytes(256, 197, D, Hd)
 
 
 def test_checkpoint_helpers_follow_the_reference_wire_format(tmp_path):
@@ -209,3 +223,78 @@ def test_checkpoint_helpers_follow_the_reference_wire_format(tmp_path):
     assert torch.allclose(big.pos_embed[:, 1:], want)
     assert torch.equal(big.head.weight, head_before)                              # mismatching head left alone
     assert torch.equal(big.blocks[1].mlp.fc1.weight, src.blocks[1].mlp.fc1.weight)
+
+
+@pytest.mark.parametrize("kind,clip", [("mgd", None), ("soft", 0.5), ("none", None)])
+def test_product_loop_equals_the_oracle_loop_on_cpu(kind, clip, monkeypatch):
+    """deltakd_amd.engine.train_one_epoch (the product's loop; model-agnostic) and oracle.engine_ref.train_one_epoch_ref (the
+    de-duplicated restatement of tools/engine.py:8-76) driven with the SAME oracle models, draws and data must produce identical
+    per-epoch statistics and identical post-epoch weights: mixup order, criterion call, accuracy targets, zero_grad / backward /
+    clip / step order, meters.  (The GPU test tests/test_engine_gpu.py then swaps the HIP models in.)"""
+    import copy
+    from deltakd_amd import engine
+    from deltakd_amd.shims import Mixup, NativeScaler
+    from oracle import engine_ref
+    s0, t = toy_pair(kind)
+    args = loss_ref.default_args(distillation_type=kind, lrkd_rank=16, epochs=1, print_freq=0, mgd_alpha=2.0, mixup=0.8, cutmix=1.0)
+    g = torch.Generator().manual_seed(5)
+    data = [(torch.randn(4, 3, 32, 32, generator=g), torch.randint(0, 10, (4,), generator=g)) for _ in range(3)]
+    keeps = [[(torch.rand(4, generator=g) > 0.2).float() for _ in range(24)] for _ in range(3)]
+    noises = [{"noise": torch.rand(4, 16, generator=g)} for _ in range(3)]
+    monkeypatch.setattr(engine, "forward_with_features", loss_ref.forward_with_features_ref)
+
+    class Crit(nn.Module):          # reference call contract; the draws of step i are consumed in order
+        def __init__(self, teacher):
+            super().__init__()
+            self.inner = loss_ref.DistillationLossRef(loss_ref.call_base_loss_ref(args), teacher, kind, args.alpha, args.tau)
+            self.step = 0
+
+        def forward(self, inputs, outputs, student, feats, labels, a):
+            self.step += 1
+            return self.inner(inputs, outputs, student, feats, labels, a, noises[self.step - 1])
+
+    class StepKeep:                 # the oracle model takes a list; hand it a fresh one per forward
+        def __init__(self, model):
+            self.model, self.i = model, 0
+            self.handle = model.register_forward_pre_hook(self)
+
+        def __call__(self, module, inp):
+            self.model.set_droppath_keep(keeps[self.i])
+            self.i += 1
+
+    # product loop
+    s_a = copy.deepcopy(s0)
+    StepKeep(s_a)
+    opt_a = torch.optim.AdamW(s_a.parameters(), lr=1e-3)
+    np.random.seed(11)
+    mix = Mixup(mixup_alpha=0.8, cutmix_alpha=1.0, num_classes=10)
+    stats_a = engine.train_one_epoch(s_a, t, [(x.clone(), y.clone()) for x, y in data], Crit(t), opt_a, NativeScaler(), clip, mix, None,
+                                     torch.device("cpu"), 0, args)
+    # oracle loop
+    s_b = copy.deepcopy(s0)
+    opt_b = torch.optim.AdamW(s_b.parameters(), lr=1e-3)
+    np.random.seed(11)
+    mix_b = engine_ref.MixupRef(mixup_alpha=0.8, cutmix_alpha=1.0, num_classes=10)
+    crit_b = loss_ref.DistillationLossRef(loss_ref.call_base_loss_ref(args), t, kind, args.alpha, args.tau)
+    stats_b, per_step = engine_ref.train_one_epoch_ref(s_b, t, [(x.clone(), y.clone()) for x, y in data], crit_b, opt_b, clip, mix_b, 0, args,
+                                                      keep_per_step=keeps, draws_per_step=noises)
+    assert len(per_step) == 3
+    for k in ("train_loss", "train_acc1", "train_acc5", "train_lr"):
+        assert abs(float(stats_a[k]) - stats_b[k]) <= 1e-6 * max(1.0, abs(stats_b[k])), (k, stats_a[k], stats_b[k])
+    for (n, a), (_, b) in zip(s_a.named_parameters(), s_b.named_parameters()):
+        assert torch.allclose(a, b, rtol=0, atol=1e-7), n
+
+
+def test_validate_equals_the_oracle_loop_on_cpu():
+    """tools/engine.py:78-104."""
+    from deltakd_amd import engine
+    from oracle import engine_ref
+    s, _ = toy_pair("soft")             # distilled student: eval mode returns the averaged heads, train-tuple branch not taken
+    g = torch.Generator().manual_seed(9)
+    data = [(torch.randn(6, 3, 32, 32, generator=g), torch.randint(0, 10, (6,), generator=g)) for _ in range(3)]
+    a = engine.validate(s, data, torch.device("cpu"), SimpleNamespace(rank=1))
+    b = engine_ref.validate_ref(s, data)
+    assert set(a) == {"val_loss", "val_acc1", "val_acc5"}
+    for k in b:
+        assert abs(float(a[k]) - b[k]) < 1e-6, (k, a[k], b[k])
+    assert not s.training

@@ -91,6 +91,13 @@ def main(argv=None):
     np.random.seed(args.seed + args.rank)
     if args.rank == 0:
         print(args)
+    if args.distillation_type == "wasskd" and args.wasskd_type != "l1":
+        # model/loss.py:200-225 of the reference calls geomloss.SamplesLoss("sinkhorn", blur=0.05): a third-party package that is in
+        # neither requirements file, is not installed here, and for which the reference holds no test vector (parity unpinned)
+        raise SystemExit(f"--wasskd-type {args.wasskd_type}: the Sinkhorn divergence of the reference comes from the third-party package "
+                         "geomloss, which is not available on this system and has no pinned oracle; only the sorted-L1 Wasserstein "
+                         "distance is implemented (model/loss.py:187-199).  Re-run with --wasskd-type l1 "
+                         "(exp/wasskd-deit-tiny.sh: WASSKD_TYPE=l1 bash exp/wasskd-deit-tiny.sh GPU_IDS MASTER_PORT).")
     teacher, student = load_teacher_student_model(args.teacher_model, args.student_model, args.drop_path_rate, args)
     student.to(device)
     teacher.to(device)
@@ -124,8 +131,6 @@ def main(argv=None):
             enable_finetune_mode(student, student_state)
         else:
             student.load_state_dict(student_state, strict=False)
-        for sh in {id(m._shadow): m._shadow for m in student.modules() if hasattr(m, "_shadow")}.values():
-            sh.optimizer_stepped(bf16_fresh=False)      # the fp32 weights changed under the bf16 copies the GEMMs read
     model = DataParallel(student, optimizer) if args.distributed else student
     model_ema = ModelEma(student, decay=args.ema_decay, optimizer=optimizer) if args.ema_decay else None
     best_val_acc = 0.0

@@ -203,6 +203,7 @@ def test_free_functions_and_aux_modules_with_the_reference_signatures():
     targets = [loss_ref.lrkd_targets_ref(o_tf[b][:, 2:], rank) for b in (0, 1, 11)]
     for p in s.parameters():
         p.grad = None
+    out, feats = forward_with_features(s, x.to(DEV))           # a block's activations are released by its first backward
     sf = [s.align[0](feats[0][:, 1:]), s.align[1](feats[1][:, 1:]), s.align[2](feats[-1][:, 1:])]
     loss2 = lrkd_loss(tf, sf, rank, 0.2, 0.3, 0.5, targets=[a.to(DEV) for a in targets])
     o_loss = sum(w * torch.nn.functional.mse_loss(a, f.reshape(-1, rank)) for w, a, f in zip((0.2, 0.3, 0.5), targets, o_sf))

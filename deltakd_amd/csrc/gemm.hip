@@ -1502,7 +1502,8 @@ extern "C" int dkd_gram(const void* A, float* C, int32_t M, int32_t N, int32_t l
   DKD_CHECK_ARG(lda % 8 == 0 && ((uintptr_t)A & 15) == 0, "gram: rows of A must be 16-byte aligned (lda=%d)", lda);
   const int KT = cdiv(M, 64), T = cdiv(N, 128);
   const int tiles = T * (T + 1) / 2;   // tile pairs t1 <= t2
-  int splits = cdiv(512, tiles);
+  int splits = 512 / tiles;            // at most ONE round of 2 workgroups per CU (rounding up left a 13-block second round at 768)
+  if (splits < 1) splits = 1;
   if (splits > cdiv(KT, 4)) splits = cdiv(KT, 4);
   if (splits < 1) splits = 1;
   const int per = cdiv(KT, splits);

@@ -123,6 +123,9 @@ _SIGS = {
     "dkd_block_bwd_workspace_bytes": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "dkd_block_bwd_workspace_carve": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(BlockGrads)]),
     "dkd_jacobi_eigh": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "dkd_lowrank_workspace_bytes": (C.c_int64, [C.c_int32, C.c_int32]),
+    "dkd_lowrank_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
+                                   C.c_void_p, C.c_void_p, C.c_void_p]),
     "dkd_adamw_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float,
                                  C.c_float, C.c_float, C.c_float, C.c_int32, C.c_float, C.c_void_p]),
 }

@@ -141,64 +141,63 @@ def align_mse_term(tap, align, shadow, target, tmap, scale, npre, mask=None):
 class LowRankTargets:
     """U_k S_k of the [B*P, Dt] teacher matrices (model/loss.py:318-324), computed as T V_k without factorising T.
 
-    Gram matrices G_l = T_l^T T_l come from the split-M MFMA wgrad kernel; their leading invariant subspace is found by
-    block subspace iteration (block b = min(Dt, 128) > rank: oversampling), all layers batched:
-        Y = G V;  V = orth(Y)   (orth: column scaling + Gram + LDS-resident Jacobi eigensolver, no Cholesky breakdown)
-    followed by one Rayleigh-Ritz step (b x b Jacobi) that orders the Ritz vectors by singular value, so column j equals
-    the j-th right singular vector up to sign (the sign LAPACK picks is arbitrary too: SURVEY.md section 0 item 9).
-    The converged basis is kept and warm-starts the next call: the teacher is frozen, so consecutive batches share their
-    principal subspace and ``warm_iters`` refinement steps per call keep it converged.  Dt <= 128 is solved exactly.
+    Gram matrices G_l = T_l^T T_l come from the split-M MFMA kernel (upper tile pairs only); their leading invariant subspace is
+    tracked by block subspace iteration with a block of 96 > rank vectors (oversampling), all layers batched, entirely inside libdkd
+    (``ops.lowrank_step``, csrc/lowrank.hip: 4 launches per step): Rayleigh-Ritz in the span of the previous basis (LDS-resident Jacobi
+    on the 96 x 96 Rayleigh quotient, at most ``ritz_sweeps`` sweeps per batch -- the basis carries over, so the diagonalisation of the
+    slowly changing quotient continues from batch to batch), a power step Y = G V W, and orthonormalisation in Ritz order; column j of
+    the result is the j-th right singular vector up to sign (the sign LAPACK picks is arbitrary too: SURVEY.md section 0 item 9).
+    The teacher is frozen, consecutive batches share their principal subspace, and ``warm_iters`` steps per call keep the basis
+    converged (and the column signs continuous from batch to batch).  A cold start runs ``cold_iters`` power steps and one converged
+    Rayleigh-Ritz step first.  Dt <= 128 is solved exactly by one Jacobi decomposition of G.
     """
+    BLOCK = 96
 
-    def __init__(self, block=96, cold_iters=16, warm_iters=1, sweeps=10, ns_iters=10):
-        self.block, self.cold_iters, self.warm_iters, self.sweeps, self.ns_iters = block, cold_iters, warm_iters, sweeps, ns_iters
+    def __init__(self, cold_iters=16, warm_iters=1, sweeps=12, ritz_sweeps=2):
+        self.cold_iters, self.warm_iters, self.sweeps, self.ritz_sweeps = cold_iters, warm_iters, sweeps, ritz_sweeps
         self.basis = None
-
-    def _orth_warm(self, Y):
-        """Newton-Schulz orthonormalisation (GEMMs only): for a warm-started basis the columns of G V are already nearly
-        orthogonal, so X <- X (3 I - X^T X) / 2 converges quadratically; X is first scaled so that sigma_max <= 1
-        (||X^T X||_1 bounds sigma_max^2), which makes the iteration safe for any input."""
-        X = Y / Y.norm(dim=1, keepdim=True).clamp_min(1e-30)
-        S = torch.bmm(X.transpose(1, 2), X)
-        X = X * torch.rsqrt(S.abs().sum(dim=1).amax(dim=1))[:, None, None]
-        for _ in range(self.ns_iters):
-            S = torch.bmm(X.transpose(1, 2), X)
-            X = torch.baddbmm(X, X, S, beta=1.5, alpha=-0.5)
-        return X
-
-    def _orth(self, Y):
-        Yn = Y / Y.norm(dim=1, keepdim=True).clamp_min(1e-30)
-        S = torch.bmm(Yn.transpose(1, 2), Yn)
-        e, Q = ops.jacobi_eigh(0.5 * (S + S.transpose(1, 2)), self.sweeps)
-        e = torch.maximum(e, e[:, :1] * 1e-12)
-        return torch.bmm(Yn, Q * torch.rsqrt(e)[:, None, :])
+        self.ritz = None            # [L, 96] Ritz values of the last call (squared singular values), device tensor
+        self._ws, self._ws_key = None, None
 
     @torch.no_grad()
-    def right_vectors(self, G, rank):
-        """G f32 [L, Dt, Dt] symmetric PSD -> V f32 [L, Dt, rank], columns by descending eigenvalue."""
+    def right_vectors(self, G, rank, want_split=False):
+        """G f32 [L, Dt, Dt] symmetric PSD (Dt > 128: only the 128 x 128 tiles on and above the diagonal are read)
+        -> V f32 [L, Dt, >= rank], columns by descending eigenvalue (+ (hi, lo) bf16 [L, rank, Dt] if ``want_split``)."""
         L, Dt, _ = G.shape
-        G = 0.5 * (G + G.transpose(1, 2))
         if Dt <= 128:
-            _, W = ops.jacobi_eigh(G, max(self.sweeps, 12))
-            return W[:, :, :rank]
-        b = min(self.block, 128)
+            G = 0.5 * (G + G.transpose(1, 2))
+            _, W = ops.jacobi_eigh(G, self.sweeps)
+            V = W[:, :, :rank].contiguous()
+            if not want_split:
+                return V
+            Vt = V.transpose(1, 2).contiguous()
+            hi = Vt.to(BF16)
+            return V, hi, (Vt - hi.float()).to(BF16)
+        b = self.BLOCK
         if rank > b:
             raise ValueError(f"lrkd rank {rank} exceeds the subspace block {b}")
-        if self.basis is None or self.basis.shape != (L, Dt, b):
+        if self._ws is None or self._ws_key != (L, Dt, G.device):
+            self._ws, self._ws_key = ops.lowrank_workspace(L, Dt, G.device), (L, Dt, G.device)
+        if self.basis is None or self.basis.shape != (L, Dt, b) or self.basis.device != G.device:
             gen = torch.Generator(device=G.device).manual_seed(1234)
-            V = self._orth(torch.randn(L, Dt, b, device=G.device, dtype=F32, generator=gen))
+            V = torch.randn(L, Dt, b, device=G.device, dtype=F32, generator=gen)
+            ops.lowrank_step(G, V, 2, self._ws)
             for _ in range(self.cold_iters):
-                V = self._orth(torch.bmm(G, V))
-            V = self._orth(V)                                 # second pass: orthonormal to fp32 roundoff
-        else:
-            V = self.basis
-            for _ in range(self.warm_iters):
-                V = self._orth_warm(torch.bmm(G, V))
-        H = torch.bmm(V.transpose(1, 2), torch.bmm(G, V))
-        _, W = ops.jacobi_eigh(0.5 * (H + H.transpose(1, 2)), self.sweeps)
-        V = torch.bmm(V, W)                                   # Ritz vectors, descending
-        self.basis = V
-        return V[:, :, :rank]
+                ops.lowrank_step(G, V, 0, self._ws)
+            ops.lowrank_step(G, V, 2, self._ws)             # second pass: orthonormal to fp32 roundoff
+            ops.lowrank_step(G, V, 3, self._ws)             # rotate the basis onto the Ritz vectors (see csrc/lowrank.hip)
+            self.basis = V
+        V = self.basis
+        for _ in range(self.warm_iters - 1):
+            ops.lowrank_step(G, V, 0, self._ws)
+        hi = lo = None
+        if want_split:
+            hi = torch.empty(L, rank, Dt, device=G.device, dtype=BF16)
+            lo = torch.empty(L, rank, Dt, device=G.device, dtype=BF16)
+        if self.ritz is None or self.ritz.shape != (L, b) or self.ritz.device != G.device:
+            self.ritz = torch.empty(L, b, device=G.device, dtype=F32)
+        ops.lowrank_step(G, V, 1, self._ws, rank=rank, hi=hi, lo=lo, evals=self.ritz, ritz_sweeps=self.ritz_sweeps)
+        return (V, hi, lo) if want_split else V
 
     @torch.no_grad()
     def __call__(self, taps, npre, rank):
@@ -209,15 +208,13 @@ class LowRankTargets:
         Ts = [t.reshape(B * N, Dt) for t in taps]
         G = torch.zeros(len(Ts), Dt, Dt, device=Ts[0].device, dtype=F32)
         for i, T in enumerate(Ts):
-            ops.gram(T, G[i], M=B * P, amap=smap)           # upper-triangular tiles only, mirrored
-        V = self.right_vectors(G, rank)
+            ops.gram(T, G[i], M=B * P, amap=smap, mirror=False)     # upper-triangular tiles only
+        _, hi, lo = self.right_vectors(G, rank, want_split=True)
         out = []
         for i, T in enumerate(Ts):
-            Vt = V[i].t().contiguous()                        # [rank, Dt]
-            hi = Vt.to(BF16)
-            lo = (Vt - hi.float()).to(BF16)                   # bf16 hi/lo split keeps ~16 bits of V through the bf16 MFMA
-            A = ops.gemm_nt(T, hi, M=B * P, amap=smap, out_f32=True)
-            ops.gemm_nt(T, lo, out=A, M=B * P, amap=smap, accumulate=True)
+            # bf16 hi/lo split of V_k^T keeps ~16 bits of V through the bf16 MFMA: A = T hi^T + T lo^T
+            A = ops.gemm_nt(T, hi[i], M=B * P, amap=smap, out_f32=True)
+            ops.gemm_nt(T, lo[i], out=A, M=B * P, amap=smap, accumulate=True)
             out.append(A)
         return out
 

@@ -90,13 +90,13 @@ def gemm_tn(a, b, out, *, M=None, N1=None, N2=None, amap=IDENT, bmap=IDENT, cols
     return out
 
 
-def gram(a, out, *, M=None, amap=IDENT):
-    """out[N, N] (f32) += a[M, N]^T a[M, N], computed on the tile pairs of the upper triangle and mirrored here (the tiles below the
-    diagonal of ``out`` must be zero on entry)."""
+def gram(a, out, *, M=None, amap=IDENT, mirror=True):
+    """out[N, N] (f32) += a[M, N]^T a[M, N], computed on the 128 x 128 tile pairs of the upper triangle; ``mirror``: fill the tiles below
+    the diagonal from their transposes (they must be zero on entry) -- ``lowrank_step`` reads the upper tiles only and does not need it."""
     assert a.dtype == BF16 and out.dtype == F32 and out.shape[0] == out.shape[1] == a.shape[1]
     N = a.shape[1]
     check(lib().dkd_gram(ptr(a), ptr(out), a.shape[0] if M is None else M, N, a.stride(0), out.stride(0), amap, stream()), "gram")
-    if N > 128:
+    if N > 128 and mirror:
         blk = torch.arange(N, device=out.device) // 128
         lower = blk[:, None] > blk[None, :]                  # tiles strictly below the diagonal
         out.copy_(torch.where(lower, out.t(), out))
@@ -294,6 +294,31 @@ def jacobi_eigh(A, sweeps=10):
     ev, order = torch.sort(ev, dim=1, descending=True)
     vec = torch.gather(vec, 2, order[:, None, :].expand(bt, n, n))
     return ev, vec
+
+
+def lowrank_workspace(L, Dt, device):
+    return torch.empty(lib().dkd_lowrank_workspace_bytes(L, Dt), device=device, dtype=torch.uint8)
+
+
+def lowrank_step(G, V, mode, ws, rank=0, hi=None, lo=None, evals=None, ritz_sweeps=2):
+    """One block-subspace-iteration step on G f32 [L, Dt, Dt] (upper 128-tiles valid), V f32 [L, Dt, 96] in place (include/dkd.h):
+    mode 0 power step, 1 tracking step (at most ``ritz_sweeps`` Jacobi sweeps of Rayleigh-Ritz, then a power step orthonormalised in Ritz
+    order; fills hi / lo bf16 [L, rank, Dt] and evals f32 [L, 96] when given), 2 orthonormalise V, 3 converged Rayleigh-Ritz in span(V)
+    (outputs as mode 1)."""
+    assert G.dtype == F32 and V.dtype == F32 and G.is_contiguous() and V.is_contiguous() and V.shape[2] == 96
+    L, Dt = G.shape[0], G.shape[1]
+    assert G.shape == (L, Dt, Dt) and V.shape[:2] == (L, Dt)
+    if hi is not None:
+        assert hi.dtype == BF16 and lo.dtype == BF16 and hi.is_contiguous() and lo.is_contiguous() and hi.shape == lo.shape == (L, rank, Dt)
+    check(lib().dkd_lowrank_step(ptr(G), ptr(V), L, Dt, mode, ritz_sweeps, rank, ptr(hi), ptr(lo), ptr(evals), ptr(ws), stream()),
+          "lowrank_step")
+    return V
+
+
+def lowrank_info(ws, L, Dt):
+    """Jacobi sweeps of the last ``lowrank_step`` per layer: int32 [L, 2] (orthonormalisation, Rayleigh-Ritz) -- diagnostics."""
+    off = lib().dkd_lowrank_workspace_bytes(L, Dt) - (L * 8 + 255) // 256 * 256
+    return ws[off:off + L * 8].view(torch.int32).view(L, 2)
 
 
 def im2col3x3(x, B, hw):

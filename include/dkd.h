@@ -244,10 +244,27 @@ int64_t dkd_block_fwd_workspace_bytes(int32_t B, int32_t N, int32_t D, int32_t H
 int64_t dkd_block_bwd_workspace_bytes(int32_t B, int32_t N, int32_t D, int32_t hidden);
 int dkd_block_bwd_workspace_carve(void* ws, int32_t B, int32_t N, int32_t D, int32_t hidden, DkdBlockGrads* gr);
 
-/* ---------------------------------------------------------------- small dense eigensolver (LRKD target, model/loss.py:321) */
+/* ---------------------------------------------------------------- LRKD target: truncated SVD without factorising T (model/loss.py:318-324) */
 /* Batched cyclic Jacobi: A f32 [batch, n, n] symmetric, n <= 128 -> evals [batch, n] (unsorted), evecs [batch, n, n]
- * (column j pairs with evals[j]).  One workgroup per matrix, LDS-resident; `sweeps` full sweeps (10 converges fp32). */
+ * (column j pairs with evals[j]).  One workgroup per matrix, LDS-resident; at most `sweeps` sweeps, stops after the first sweep that
+ * rotates nothing (10 converge fp32). */
 int dkd_jacobi_eigh(const float* A, float* evals, float* evecs, int32_t batch, int32_t n, int32_t sweeps, void* stream);
+
+/* One step of block subspace iteration (block of 96 vectors) on L symmetric PSD matrices G f32 [L, Dt, Dt] of which only the
+ * 128 x 128 tiles on and above the diagonal need to be valid (what dkd_gram writes), all layers in the same launches (csrc/lowrank.hip).
+ * V f32 [L, Dt, 96] is updated in place:
+ *   mode 0: V <- orth(G V)        a power step (cold start); orthonormalised through the eigen-decomposition of (G V)^T (G V)
+ *   mode 1: the tracking step run once per batch, V orthonormal on entry (the previous batch's result):
+ *           V <- orth(G V W), W = eigenvectors of V^T G V by at most `ritz_sweeps` Jacobi sweeps (0: keep the basis as it is),
+ *           columns by descending Ritz value, orthonormalised in that order (Cholesky)
+ *   mode 2: V <- orth(V)
+ *   mode 3: V <- V W, Ritz vectors of G in span(V) run to convergence, V orthonormal on entry (ends a cold start)
+ * Optional outputs of modes 1 and 3: evals f32 [L, 96] (Ritz values of V^T G V = squared singular values of T, descending), and
+ * v_hi / v_lo bf16 [L, rank, Dt]: V[:, :rank]^T split as hi = bf16(v), lo = bf16(v - hi) -- the B operands of the projection GEMMs
+ * U_k S_k = T V_k.   ws: dkd_lowrank_workspace_bytes(L, Dt) bytes of scratch, 256-byte aligned.  Dt % 32 == 0, Dt >= 128. */
+int64_t dkd_lowrank_workspace_bytes(int32_t L, int32_t Dt);
+int dkd_lowrank_step(const float* G, float* V, int32_t L, int32_t Dt, int32_t mode, int32_t ritz_sweeps, int32_t rank, void* v_hi,
+                     void* v_lo, float* evals, void* ws, void* stream);
 
 /* ---------------------------------------------------------------- optimizer ([3P] torch.optim.AdamW via timm create_optimizer) */
 /* One launch over a flat parameter segment; optionally refreshes the bf16 shadow copy used by the GEMMs. */

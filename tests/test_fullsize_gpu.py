@@ -175,6 +175,50 @@ def test_lowrank_targets_properties_full_size(ops):
     assert res[0] > res[1] > res[2] > 0
 
 
+def test_lowrank_warm_start_tracks_real_teacher_taps(models):
+    """The warm-started tracking step (ONE power + Rayleigh-Ritz step per batch) on REAL teacher taps over CHANGING batches: the
+    deit_base_distilled teacher of the headline config, 6 different batches of 32 images, taps of blocks 0, 1, 11, each batch compared
+    with torch.linalg.svd of that batch's own [32 * 196, 768] matrices (the reference's computation, model/loss.py:321).
+    Sign- and rotation-invariant measures of what the loss consumes, U_k S_k = T V_k (k = 64):
+      * captured energy ||T V_k||_F^2 / sum_{i<=k} sigma_i^2  (1 = the optimal rank-k subspace);
+      * the singular values themselves, column by column;
+      * leading columns against the SVD's, up to sign.
+    The first call is a cold start (16 power steps); calls 2-6 are warm."""
+    from deltakd_amd.losses import LowRankTargets
+    t = models
+    solver = LowRankTargets()
+    k, npre = 64, 2
+    worst_energy, worst_sv = 1.0, 0.0
+    for call in range(6):
+        x = rnd(32, 3, 224, 224, seed=100 + call)
+        with torch.no_grad():
+            _, taps = t.forward_with_taps(x, (0, 1, 11))
+        sel = [taps[0], taps[1], taps[11]]
+        tg = solver(sel, npre, k)
+        for li, (tap, got) in enumerate(zip(sel, tg)):
+            T = tap[:, npre:].reshape(-1, tap.shape[-1]).float().cpu().double()
+            U, S, Vh = torch.linalg.svd(T, full_matrices=False)
+            ref = (U[:, :k] * S[:k])
+            got = got.cpu().double()
+            energy = (got ** 2).sum().item() / (S[:k] ** 2).sum().item()
+            worst_energy = min(worst_energy, energy)
+            sv = got.norm(dim=0)
+            rel_sv = ((sv - S[:k]).abs() / S[0]).max().item()
+            worst_sv = max(worst_sv, rel_sv)
+            print(f"call {call} layer {li}: captured energy {energy:.5f}  max |sigma err| / sigma_1 {rel_sv:.2e}  "
+                  f"sigma_1 {S[0].item():.1f} sigma_64 {S[63].item():.1f} sigma_97 {S[96].item():.1f}")
+            assert energy > 0.99, (call, li, energy)
+            assert rel_sv < 2e-2, (call, li, rel_sv)
+            # columns whose singular value is separated from its neighbours by > 5 % are well conditioned: compare up to sign
+            gap = torch.minimum((S[:k] - S[1:k + 1]), torch.cat([torch.tensor([1e9], dtype=S.dtype), S[:k - 1] - S[1:k]])) / S[:k]
+            well = torch.nonzero(gap > 0.05).flatten()[:8]
+            for j in well.tolist():
+                sgn = torch.sign((got[:, j] * ref[:, j]).sum())
+                err = (got[:, j] * sgn - ref[:, j]).norm() / ref[:, j].norm()
+                assert err < 5e-2, (call, li, j, err.item(), gap[j].item())
+    assert worst_energy <= 1.0 + 1e-3
+
+
 @pytest.mark.parametrize("epi", ["bias", "gelu"])
 def test_wide_gemm_ragged_rows(ops, epi):
     """The persistent 256 x 256 kernel on an M that is odd and not a multiple of 256 (edge tiles: clamped A rows, masked stores, the

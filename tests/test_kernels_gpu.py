@@ -388,6 +388,69 @@ def test_jacobi_eigh(ops, n, batch):
     close(vec.transpose(1, 2) @ vec, eye, 2e-5, "orthonormal")
 
 
+@pytest.mark.parametrize("Dt", [768, 384, 1024])
+def test_lowrank_step_kernels(ops, Dt):
+    """csrc/lowrank.hip against torch.linalg.eigh: orthonormalisation (mode 2), power steps (mode 0), the tracking step (mode 1:
+    Ritz values / vectors sorted, hi/lo bf16 split of V_k^T), and that ONLY the 128 x 128 tiles on and above the diagonal of G are read
+    (the rest is filled with NaN)."""
+    L, b, r = 3, 96, 64
+    g = torch.Generator().manual_seed(5)
+    Gs, refs = [], []
+    for l in range(L):
+        q = torch.linalg.qr(torch.randn(Dt, Dt, generator=g, dtype=torch.float64))[0]
+        lam = torch.cat([torch.linspace(50, 8, 40, dtype=torch.float64), 6.0 * torch.exp(-torch.arange(Dt - 40, dtype=torch.float64) / 25.0) + 0.05])
+        G = (q * lam) @ q.t()
+        refs.append((lam, q))
+        Gs.append(G.float())
+    G = torch.stack(Gs).to(dev())
+    blk = torch.arange(Dt, device=dev()) // 128
+    Gu = torch.where((blk[:, None] > blk[None, :])[None], torch.full_like(G, float("nan")), G).contiguous()
+    ws = ops.lowrank_workspace(L, Dt, G.device)
+    V = torch.randn(L, Dt, b, device=dev(), generator=torch.Generator(device=dev()).manual_seed(1))
+    ops.lowrank_step(Gu, V, 2, ws)
+    eye = torch.eye(b, device=dev()).expand(L, b, b)
+    close(V.transpose(1, 2) @ V, eye, 1e-4, "orth(V)")
+    for _ in range(16):
+        ops.lowrank_step(Gu, V, 0, ws)
+    ops.lowrank_step(Gu, V, 2, ws)
+    close(V.transpose(1, 2) @ V, eye, 2e-5, "orthonormal after power steps")
+    hi = torch.empty(L, r, Dt, device=dev(), dtype=BF16)
+    lo = torch.empty(L, r, Dt, device=dev(), dtype=BF16)
+    ev = torch.empty(L, b, device=dev())
+
+    def check(tag, vec_tol):
+        close(V.transpose(1, 2) @ V, eye, 5e-5, tag + ": Ritz vectors orthonormal")
+        for l in range(L):
+            lam, q = refs[l]
+            assert (ev[l, 1:] <= ev[l, :-1] + 1e-6 * ev[l, 0]).all(), tag + ": Ritz values not sorted"
+            assert (ev[l, :r].double().cpu() - lam[:r]).abs().max().item() <= 2e-4 * lam[0].item(), tag + ": Ritz values"
+            lead = 40                                   # the well-separated leading eigenvectors, up to sign
+            dots = (V[l, :, :lead].double().cpu() * q[:, :lead]).sum(0).abs()
+            assert dots.min().item() > 1 - vec_tol, (tag, dots.min().item())
+            Pr = V[l, :, :r].double().cpu()             # rank-r projector captures the leading invariant subspace
+            assert ((Pr.t() @ q[:, :r]) ** 2).sum().item() > r - 1e-2, tag
+            Vt = V[l, :, :r].t()
+            close(hi[l].float() + lo[l].float(), Vt, 1e-4, tag + ": hi + lo")
+            assert torch.equal(hi[l], Vt.to(BF16)), tag
+
+    ops.lowrank_step(Gu, V, 3, ws, rank=r, hi=hi, lo=lo, evals=ev)          # converged Rayleigh-Ritz in the span reached
+    check("mode 3", 1e-3)
+    for it in range(3):                     # tracking steps on the same G (2 Jacobi sweeps each at most): stays converged and sorted
+        ops.lowrank_step(Gu, V, 1, ws, rank=r, hi=hi, lo=lo, evals=ev, ritz_sweeps=2)
+        assert torch.isfinite(V).all()
+    check("mode 1", 1e-3)
+    assert int(ops.lowrank_info(ws, L, Dt)[:, 1].max()) <= 2
+    # a rotated basis of the same subspace and no sweeps at all: the step must still return an orthonormal basis of span(G V) (to
+    # fp32 roundoff x the conditioning of (G V)^T (G V), which is what the Ritz rotation keeps near 1 in normal operation)
+    rot = torch.linalg.qr(torch.randn(b, b, generator=g))[0].to(dev())
+    V2 = (V @ rot).contiguous()
+    ops.lowrank_step(Gu, V2, 1, ws, ritz_sweeps=0)
+    close(V2.transpose(1, 2) @ V2, eye, 2e-3, "orthonormal without Ritz rotation")
+    for l in range(L):
+        q = refs[l][1]
+        assert ((V2[l].double().cpu().t() @ q[:, :r]) ** 2).sum().item() > r - 1e-2
+
+
 def test_lowrank_targets_vs_svd(ops):
     """Dt = 768 (subspace iteration + Rayleigh-Ritz path): U_k S_k against torch.linalg.svd on the host, up to column sign.
     Cold start, then a warm-started call on a different batch drawn from the same feature distribution."""

@@ -53,7 +53,7 @@ def make_args(cfg, batch, epochs=1):
     return SimpleNamespace(**a)
 
 
-def cpu_baseline(cfg, batch=32, steps=3):
+def cpu_baseline(cfg, batch=16, steps=6):
     """The oracle (CPU restatement of the reference path, fp32, torch CPU threads) timed on this host."""
     from oracle import loss_ref, vit_ref
     torch.manual_seed(42)
@@ -142,19 +142,24 @@ def main():
     scaler = NativeScaler()
 
     g = torch.Generator(device=dev).manual_seed(42 + rank)
-    samples = torch.randn(a.batch, 3, 224, 224, device=dev, generator=g)
-    targets = torch.randint(0, 1000, (a.batch,), device=dev, generator=g)
+    n_distinct = 4                       # distinct synthetic batches, rotated: the LRKD subspace tracking sees changing teacher taps
+    pool = [(torch.randn(a.batch, 3, 224, 224, device=dev, generator=g), torch.randint(0, 1000, (a.batch,), device=dev, generator=g))
+            for _ in range(n_distinct)]
 
-    class Loader:                        # K identical synthetic batches already resident in HBM; mixup gets a fresh copy
+    class Loader:                        # K synthetic batches already resident in HBM (4 distinct, rotated); mixup gets a fresh copy
         def __init__(self, n):
             self.n = n
+            self.i = 0
 
         def __len__(self):
             return self.n
 
         def __iter__(self):
             for _ in range(self.n):
-                yield samples.clone(), targets
+                x, y = pool[Loader.pos % n_distinct]
+                Loader.pos += 1
+                yield x.clone(), y
+    Loader.pos = 0
 
     def run(n):
         return train_one_epoch(model, teacher, Loader(n), criterion, optimizer, scaler, None, mixup_fn, None, dev, 0, args)
@@ -186,9 +191,28 @@ def main():
 
     # dominant kernel = the NT-GEMM symbol with the largest summed duration in the last timed step (teacher forward is
     # ~82 % of the step's FLOPs); achieved = its algorithmic FLOPs (2 M N K per launch) / its HIP-event time.
-    per = ops.probe_end()
+    fam = ops.probe_end_ex()            # {family: (flops, bytes, ms, launches)}
+    per = {k: (v[0], v[2], v[3]) for k, v in fam.items() if k in ops.PROBE_SYMBOLS}
     dom = max(per, key=lambda k: per[k][1]) if per else None
     flops, ms, launches = per[dom] if dom else (0.0, 0.0, 0)
+    # student backward + distillation-loss path (north_star: ">= 40 % MFMA on the student backward + distill-loss path"): every
+    # launch of the 12 dkd_block_bwd calls and of the fused loss kernels in the last (single-stream) step, under HIP events
+    sb, sl = fam.get("student_block_bwd", (0.0, 0.0, 0.0, 0)), fam.get("loss_kernels", (0.0, 0.0, 0.0, 0))
+    sf = fam.get("student_block_fwd", (0.0, 0.0, 0.0, 0))
+    st_ms = sb[2] + sl[2]
+    roofline_student = None
+    if st_ms > 0:
+        roofline_student = {
+            "path": "student block backward (dkd_block_bwd x depth) + fused loss kernels, last timed step, HIP events",
+            "flop": sb[0] + sl[0], "algorithmic_bytes": sb[1] + sl[1], "ms": st_ms, "launch_groups": sb[3] + sl[3],
+            "mfma": {"achieved": (sb[0] + sl[0]) / (st_ms * 1e-3) / 1e12, "peak": 2500.0, "unit": "TFLOP/s",
+                     "frac": (sb[0] + sl[0]) / (st_ms * 1e-3) / 1e12 / 2500.0},
+            "hbm": {"achieved": (sb[1] + sl[1]) / (st_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
+                    "frac": (sb[1] + sl[1]) / (st_ms * 1e-3) / 1e9 / 8000.0},
+            "block_bwd_ms": sb[2], "loss_ms": sl[2],
+            "student_block_fwd": {"ms": sf[2], "tflops": sf[0] / (sf[2] * 1e-3) / 1e12 if sf[2] else 0.0,
+                                  "gbps": sf[1] / (sf[2] * 1e-3) / 1e9 if sf[2] else 0.0},
+        }
     achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
     traffic = None
     tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")     # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this command
@@ -201,7 +225,7 @@ def main():
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
         "config": {"workload": f"exp/{a.config}-deit-tiny.sh: {cfg['student']} <- {cfg['teacher']}, {cfg['distillation_type']}, "
-                               f"bs {a.batch}/GPU, 3x224x224 synthetic, 1000 classes, mixup/cutmix on, drop_path 0.1, AdamW",
+                               f"bs {a.batch}/GPU, 3x224x224 synthetic ({n_distinct} distinct batches rotated), 1000 classes, mixup/cutmix on, drop_path 0.1, AdamW",
                    "global_batch": world * a.batch, "parallelism": f"dp{world}",
                    "model_flops_per_image": f_img, "step_mfma_frac_of_2.5PF": ips * f_img / (world * 2.5e15),
                    "train_loss": stats.get("train_loss")},
@@ -210,6 +234,7 @@ def main():
                      "flop_per_launch_avg": flops / max(launches, 1),
                      "other_gemm_kernels": {k: {"tflops": v[0] / (v[1] * 1e-3) / 1e12, "launches": v[2], "sum_ms": v[1]}
                                             for k, v in per.items() if k != dom}},
+        "roofline_student": roofline_student,
     }
     if rank == 0:
         if world == 1 and not a.no_cpu_baseline:

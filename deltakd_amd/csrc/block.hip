@@ -46,7 +46,16 @@ extern "C" int dkd_blocks_fwd(const DkdBlock* blocks, int32_t n_blocks, void* st
   for (int i = 0; i < n_blocks; ++i) {
     const DkdBlock& b = blocks[i];
     DKD_CHECK_ARG(b.x && b.x1 && b.x2 && b.y1 && b.qkv && b.o && b.y2 && b.h, "blocks_fwd: block %d has a null buffer", i);
-    TRY(block_fwd(b, stream));
+    if (b.pre) {        // training forward (activations saved): probed as a whole for bench.py's student roofline
+      const double M = (double)b.B * b.N, D = b.D, Hd = b.hidden;
+      const double flops = 2.0 * M * (4.0 * D * D + 2.0 * D * Hd) + 4.0 * (double)b.B * b.N * b.N * D;
+      // x in, x1 in+out, x2 out (f32); y1, qkv, o, y2, pre, h written (+ qkv, o, y1, y2, h read back by the next kernel of the chain)
+      const double bytes = M * (D * 4.0 * 4 + (D * 2.0 * (1 + 3 + 1 + 1) + Hd * 2.0 * 2) * 2 + (b.tap ? D * 2.0 : 0.0));
+      DkdProbeScope probe(5, flops, bytes, as_stream(stream));
+      TRY(block_fwd(b, stream));
+    } else {
+      TRY(block_fwd(b, stream));
+    }
   }
   return DKD_OK;
 }
@@ -57,6 +66,13 @@ extern "C" int dkd_block_bwd(const DkdBlock* bp, const DkdBlockGrads* gp, void* 
   const DkdBlockGrads& r = *gp;
   DKD_CHECK_ARG(r.g && r.dF && r.dH && r.dqkv && r.dT && b.pre && b.mean1 && b.lse, "block_bwd: missing buffer (was the forward run with saves?)");
   const int M = b.B * b.N, D = b.D, Hd = b.hidden;
+  // algorithmic work of one block's backward (bench.py, roofline_student): dgrad + wgrad = 2x the forward GEMM FLOPs, attention
+  // backward 2x its forward; bytes = every tensor the pass must touch ONCE: g in/out, x, x1 (f32), the saved bf16 activations y1, qkv, o,
+  // y2, pre, h, and the tap gradient -- 30 D + 4 hidden (+ 2 D) bytes per token row
+  const double Md = (double)M;
+  const double bwd_flops = 2.0 * (2.0 * Md * (4.0 * D * D + 2.0 * (double)D * Hd) + 4.0 * (double)b.B * b.N * b.N * D);
+  const double bwd_bytes = Md * (30.0 * D + 4.0 * Hd + (r.gtap ? 2.0 * D : 0.0));
+  DkdProbeScope probe(3, bwd_flops, bwd_bytes, as_stream(st));
   // ---- MLP branch
   TRY(dkd_scale_cast_bf16(r.g, D, ID, b.s2, b.N, r.gtap, 0, D, r.dF, D, M, D, st));
   DkdGemm g = mk(r.dF, b.fc2_wt, r.dH, M, Hd, D);
@@ -77,7 +93,9 @@ extern "C" int dkd_block_bwd(const DkdBlock* bp, const DkdBlockGrads* gp, void* 
   g = mk(dFa, b.proj_wt, r.dT, M, D, D);
   TRY(dkd_gemm_nt(&g, st));
   TRY(dkd_attn_bwd(b.qkv, b.o, r.dT, b.lse, r.dqkv, b.B, b.N, b.H, st));
-  if (all4) {
+  if (all4 && r.defer_wgrad) {
+    // the caller launches dkd_gemm_tn_group({dF, h}, {dH, y2}, {dF2, o}, {dqkv, y1}) itself
+  } else if (all4) {
     const DkdTnProblem w[4] = {{r.dF, b.h, r.d_fc2_w, r.d_fc2_b, M, D, Hd, D, Hd, Hd, ID, ID},
                                {r.dH, b.y2, r.d_fc1_w, r.d_fc1_b, M, Hd, D, Hd, D, D, ID, ID},
                                {dFa, b.o, r.d_proj_w, r.d_proj_b, M, D, D, D, D, D, ID, ID},

@@ -108,4 +108,19 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 
 static inline hipStream_t as_stream(void* s) { return (hipStream_t)s; }
+
+// Launch probe of bench.py (api.hip): while dkd_probe_begin() .. dkd_probe_end*() is active, the scope brackets the launches made
+// inside it with HIP events recorded on THEIR stream and files them under `sym` with their algorithmic FLOPs / bytes.
+//   0 gemm_nt_kernel<128>   1 gemm_nt_kernel<64>   2 gemm_nt256_kernel   3 student block backward (all launches of dkd_block_bwd)
+//   4 fused loss kernels    5 student block forward (training)
+constexpr int DKD_PROBE_SYMS = 6;
+struct DkdProbeScope {
+  bool on;
+  int sym;
+  double flops, bytes;
+  hipEvent_t e0, e1;
+  hipStream_t st;
+  DkdProbeScope(int sym, double flops, double bytes, hipStream_t s);
+  ~DkdProbeScope();
+};
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }

@@ -1207,69 +1207,6 @@ __global__ __launch_bounds__(256, 2) void gemm_tn192g_kernel(const TnGroup grp) 
 
 }  // namespace
 
-// ---- optional launch probe (bench.py): HIP events around every NT-GEMM launch, on the stream it is launched on.
-namespace {
-struct ProbeRec {
-  int sym;
-  double flops;
-  hipEvent_t e0, e1;
-};
-std::mutex g_probe_mu;
-bool g_probe_on = false;
-std::vector<ProbeRec> g_probe;
-struct ProbeScope {
-  bool on;
-  ProbeRec rec;
-  hipStream_t st;
-  ProbeScope(int sym, double flops, hipStream_t s) : on(false), st(s) {
-    std::lock_guard<std::mutex> lk(g_probe_mu);
-    if (!g_probe_on) return;
-    on = true;
-    rec.sym = sym;
-    rec.flops = flops;
-    (void)hipEventCreate(&rec.e0);
-    (void)hipEventCreate(&rec.e1);
-    (void)hipEventRecord(rec.e0, st);
-  }
-  ~ProbeScope() {
-    if (!on) return;
-    (void)hipEventRecord(rec.e1, st);
-    std::lock_guard<std::mutex> lk(g_probe_mu);
-    g_probe.push_back(rec);
-  }
-};
-}  // namespace
-
-extern "C" int dkd_probe_begin(void) {
-  std::lock_guard<std::mutex> lk(g_probe_mu);
-  g_probe.clear();
-  g_probe_on = true;
-  return DKD_OK;
-}
-
-// sym 0 = gemm_nt_kernel<128>, 1 = gemm_nt_kernel<64>, 2 = gemm_nt256_kernel.  Arrays of 3.
-extern "C" int dkd_probe_end(double* flops, double* ms, int32_t* launches) {
-  std::lock_guard<std::mutex> lk(g_probe_mu);
-  g_probe_on = false;
-  for (int i = 0; i < 3; ++i) {
-    flops[i] = 0.0;
-    ms[i] = 0.0;
-    launches[i] = 0;
-  }
-  for (auto& r : g_probe) {
-    (void)hipEventSynchronize(r.e1);
-    float t = 0.f;
-    (void)hipEventElapsedTime(&t, r.e0, r.e1);
-    flops[r.sym] += r.flops;
-    ms[r.sym] += t;
-    launches[r.sym] += 1;
-    (void)hipEventDestroy(r.e0);
-    (void)hipEventDestroy(r.e1);
-  }
-  g_probe.clear();
-  return DKD_OK;
-}
-
 extern "C" int dkd_gemm_nt(const DkdGemm* gp, void* stream) {
   DKD_CHECK_ARG(gp && gp->A && gp->B && gp->C, "gemm_nt: null operand");
   const DkdGemm& g = *gp;
@@ -1325,14 +1262,14 @@ extern "C" int dkd_gemm_nt(const DkdGemm* gp, void* stream) {
       DkdGemm g1 = g;
       g1.M = M1;
       {
-        ProbeScope probe1(2, 2.0 * g1.M * g1.N * g1.K, as_stream(stream));
+        DkdProbeScope probe1(2, 2.0 * g1.M * g1.N * g1.K, 0.0, as_stream(stream));
         hipLaunchKernelGGL((gemm_nt256_kernel<0, 0, 4, 3>), dim3(n_cu), dim3(512), 0, as_stream(stream), g1, panels1 * tn);
         DKD_CHECK_LAUNCH("gemm_nt256");
       }
       return dkd_gemm_nt(&g2, stream);
     }
   }
-  ProbeScope probe(wide ? 2 : (narrow ? 1 : 0), 2.0 * g.M * g.N * g.K, as_stream(stream));
+  DkdProbeScope probe(wide ? 2 : (narrow ? 1 : 0), 2.0 * g.M * g.N * g.K, 0.0, as_stream(stream));
   if (wide) {
 #ifndef DKD_NT256_ABL
 #define DKD_NT256_ABL 0

@@ -197,6 +197,8 @@ extern "C" int dkd_logit_loss(const float* z, const float* soft_target, const in
   DKD_CHECK_ARG((soft_target != nullptr) != (labels != nullptr), "logit_loss: exactly one of soft_target / labels");
   DKD_CHECK_ARG(kd_mode >= 0 && kd_mode <= 2, "logit_loss: kd_mode %d", kd_mode);
   DKD_CHECK_ARG(kd_mode == 0 || (z_kd && z_t && dz_kd), "logit_loss: distillation needs z_kd, z_t, dz_kd");
+  // algorithmic bytes: logits + targets read, gradients written, per head
+  DkdProbeScope probe(4, 0.0, (double)B * C * 4.0 * (kd_mode ? 6.0 : (soft_target ? 3.0 : 2.0)), as_stream(stream));
   hipLaunchKernelGGL(logit_loss_kernel, dim3(cdiv(B, 4)), dim3(256), 0, as_stream(stream), z, soft_target, labels, smoothing, kd_mode, z_kd,
                      z_t, tau, w_base, w_kd, losses, dz, dz_kd, B, C);
   DKD_CHECK_LAUNCH("logit_loss");
@@ -209,6 +211,9 @@ extern "C" int dkd_mse_loss(const void* a, int32_t a_is_f32, int32_t lda, const 
   DKD_CHECK_ARG(a && t && loss && M > 0 && D > 0, "mse_loss: null operand");
   DKD_CHECK_ARG(D % 4 == 0 && lda % 4 == 0 && ldt % 4 == 0 && (!da || ldda % 4 == 0), "mse_loss: D/ld must be multiples of 4");
   DKD_CHECK_ARG((long)M * (D / 4) < (1L << 31), "mse_loss: M * D / 4 must be below 2^31");
+  // algorithmic bytes: read a, read t, write da
+  DkdProbeScope probe(4, 0.0, (double)M * D * ((a_is_f32 ? 4.0 : 2.0) + (t_is_f32 ? 4.0 : 2.0) + (da ? (da_is_f32 ? 4.0 : 2.0) : 0.0)),
+                      as_stream(stream));
   // every block ends with one atomic on the SAME address (~23 ns each, serialised): 512 blocks, not 2048
   hipLaunchKernelGGL(mse_loss_kernel, dim3(grid_for((long)M * D / 4, 256, 512)), dim3(256), 0, as_stream(stream), a, a_is_f32, lda, t,
                      t_is_f32, ldt, tmap, mask, w_over_denom, loss, da, da_is_f32, ldda, M, D);

@@ -301,6 +301,7 @@ extern "C" int dkd_sort_l1_loss(const void* s, int32_t s_is_f32, const void* t, 
   dim3 grid(cdiv(D, SL_COLS), B);
   int rc;
   hipStream_t st = as_stream(stream);
+  DkdProbeScope probe(4, 0.0, (double)B * P * D * ((s_is_f32 ? 4.0 : 2.0) + (t_is_f32 ? 4.0 : 2.0) + (ds_is_f32 ? 4.0 : 2.0)), st);
   if (s_is_f32)
     rc = t_is_f32 ? launch_sort<true, true>(ds_is_f32, grid, smem, st, s, t, ldt, tmap, w, loss, ds, P, D)
                   : launch_sort<true, false>(ds_is_f32, grid, smem, st, s, t, ldt, tmap, w, loss, ds, P, D);
@@ -319,6 +320,7 @@ extern "C" int dkd_normalize_mse(const float* s, const void* t_hat, const float*
                                  int32_t ldds, int32_t M, int32_t D, void* stream) {
   DKD_CHECK_ARG(s && t_hat && loss && ds, "normalize_mse: null operand");
   DKD_CHECK_ARG(M > 0 && D % 4 == 0 && D <= 1024 && ldds % 4 == 0, "normalize_mse: need D %% 4 == 0, D <= 1024 (D=%d)", D);
+  DkdProbeScope probe(4, 0.0, (double)M * D * (4.0 + 2.0 + 2.0), as_stream(stream));
   hipLaunchKernelGGL(normalize_mse_kernel, dim3(cdiv(M, 4)), dim3(256), 0, as_stream(stream), s, (const bf16_t*)t_hat, w_scalar, w_over_denom,
                      loss, (bf16_t*)ds, ldds, M, D);
   DKD_CHECK_LAUNCH("normalize_mse");
@@ -338,6 +340,7 @@ extern "C" int dkd_diffkd_prepare(const void* t, int32_t ldt, DkdRowMap tmap, co
 extern "C" int dkd_dropout_mse(const float* a, const float* t, const float* keep, float keep_scale, float w_over_denom, float* loss, void* da,
                                int64_t n, void* stream) {
   DKD_CHECK_ARG(a && t && loss && da && n > 0 && n % 4 == 0, "dropout_mse: bad arguments");
+  DkdProbeScope probe(4, 0.0, (double)n * (4.0 + 4.0 + (keep ? 4.0 : 0.0) + 2.0), as_stream(stream));
   hipLaunchKernelGGL(dropout_mse_kernel, dim3(grid_for(n / 4, 256, 2048)), dim3(256), 0, as_stream(stream), a, t, keep, keep_scale,
                      w_over_denom, loss, (bf16_t*)da, (long)(n / 4));
   DKD_CHECK_LAUNCH("dropout_mse");

@@ -93,7 +93,11 @@ class DataParallel(nn.Module):
         if cur is not None:
             if self._comm_stream is None:
                 self._comm_stream = torch.cuda.Stream()
-            self._comm_stream.wait_stream(cur)          # the gradient kernels of blocks >= idx are enqueued on `cur`
+            self._comm_stream.wait_stream(cur)          # the gradient kernels of blocks >= idx are enqueued on `cur` ...
+            from .vit import wgrad_stream_of
+            side = wgrad_stream_of(self.module)
+            if side is not None:
+                self._comm_stream.wait_stream(side)     # ... and their weight gradients on the model's wgrad stream (deltakd_amd.vit)
             with torch.cuda.stream(self._comm_stream):
                 for i, (s, e) in rng.items():
                     self._reduce(flats[i][s:e])

@@ -60,7 +60,7 @@ class Block(C.Structure):
 class BlockGrads(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("g", "gtap", "d_ln1_w", "d_ln1_b", "d_ln2_w", "d_ln2_b", "d_qkv_w", "d_qkv_b",
                                           "d_proj_w", "d_proj_b", "d_fc1_w", "d_fc1_b", "d_fc2_w", "d_fc2_b", "dF", "dH", "dqkv", "dT",
-                                          "ln_ws", "dF2")]
+                                          "ln_ws", "dF2")] + [("defer_wgrad", C.c_int32)]
 
 
 _lib = None
@@ -115,6 +115,7 @@ _SIGS = {
                                   C.c_void_p]),
     "dkd_probe_begin": (C.c_int, []),
     "dkd_probe_end": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int32)]),
+    "dkd_probe_end_ex": (C.c_int, [C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int32)]),
     "dkd_blocks_fwd": (C.c_int, [C.POINTER(Block), C.c_int32, C.c_void_p]),
     "dkd_block_bwd": (C.c_int, [C.POINTER(Block), C.POINTER(BlockGrads), C.c_void_p]),
     "dkd_layernorm_bwd_workspace_bytes": (C.c_int64, [C.c_int32, C.c_int32]),

@@ -378,6 +378,7 @@ def dropout_mse(a, t, keep, keep_scale, loss, w_over_denom):
 
 
 PROBE_SYMBOLS = ("gemm_nt_kernel<128>", "gemm_nt_kernel<64>", "gemm_nt256_kernel")
+PROBE_FAMILIES = PROBE_SYMBOLS + ("student_block_bwd", "loss_kernels", "student_block_fwd")
 
 
 def probe_begin():
@@ -390,6 +391,14 @@ def probe_end():
     fl, ms, n = (C.c_double * 3)(), (C.c_double * 3)(), (C.c_int32 * 3)()
     check(lib().dkd_probe_end(fl, ms, n), "probe_end")
     return {PROBE_SYMBOLS[i]: (fl[i], ms[i], n[i]) for i in range(3) if n[i]}
+
+
+def probe_end_ex():
+    """-> {family: (flops, bytes, ms, launches)} over PROBE_FAMILIES for the launches since probe_begin()."""
+    n = len(PROBE_FAMILIES)
+    fl, by, ms, cnt = (C.c_double * n)(), (C.c_double * n)(), (C.c_double * n)(), (C.c_int32 * n)()
+    check(lib().dkd_probe_end_ex(n, fl, by, ms, cnt), "probe_end_ex")
+    return {PROBE_FAMILIES[i]: (fl[i], by[i], ms[i], cnt[i]) for i in range(n) if cnt[i]}
 
 
 def mixup_(x, lam, box=None):

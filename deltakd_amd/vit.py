@@ -17,6 +17,8 @@ Execution model (MI355X-first, not a module-per-op graph):
     by the fc2 GEMM epilogue as a second output of the same kernel -- no forward hooks, no extra pass.
 """
 import math
+import os
+import weakref
 from typing import List, Optional, Sequence
 
 import torch
@@ -320,24 +322,66 @@ def _block_forward_train(x, B, N, blk: Block, sh: Shadow, s1, s2, want_tap: bool
     return x2, tap, (bs, slab16, slab32, x, s1, s2)
 
 
-def _backward_workspace(model, bs, dev):
-    """The scratch of dkd_block_bwd, shared by all blocks of a model (size from the library: dkd_block_bwd_workspace_bytes)."""
-    ws = getattr(model, "_bwd_ws", None)
+_RUNTIME = weakref.WeakKeyDictionary()      # model -> dict of per-process runtime objects (workspaces, streams, events): never copied
+                                            # or pickled with the module
+
+
+def _rt(model):
+    d = _RUNTIME.get(model)
+    if d is None:
+        d = _RUNTIME[model] = {}
+    return d
+
+
+def _backward_workspace(model, bs, dev, which=0):
+    """The scratch of dkd_block_bwd, shared by all blocks of a model (size from the library: dkd_block_bwd_workspace_bytes).  Two of
+    them alternate when the weight gradients run on their own stream (they read dF / dH / dF2 / dqkv of block i while block i-1 runs)."""
+    pool = _rt(model).setdefault("bwd_ws", {})
+    ws = pool.get(which)
     need = ffi.lib().dkd_block_bwd_workspace_bytes(bs.B, bs.N, bs.D, bs.hidden)
     if ws is None or ws.numel() < need or ws.device != dev:
         ws = torch.empty(need, device=dev, dtype=torch.uint8)
-        model._bwd_ws = ws
+        pool[which] = ws
     return ws
+
+
+def _wgrad_stream(model, dev):
+    """Side stream for the four weight gradients of a block (one grouped launch: ~1.5 short blocks per CU that spend their time in
+    the ring fill and in f32 atomics of partial tiles -- latency, not throughput): issued there, the launch overlaps the next
+    block's backward instead of standing between two of its kernels.  DKD_NO_WGRAD_OVERLAP=1 keeps everything on one stream."""
+    if os.environ.get("DKD_NO_WGRAD_OVERLAP"):
+        return None
+    rt = _rt(model)
+    st = rt.get("wgrad_side")
+    if st is None or st.device != dev:
+        st = rt["wgrad_side"] = torch.cuda.Stream(device=dev)
+        rt["wgrad_done"], rt["bwd_parity"] = [None, None], 0
+        rt["wgrad_events"] = [torch.cuda.Event(), torch.cuda.Event()]
+    return st
+
+
+def wgrad_stream_of(model):
+    """The stream a model's weight gradients are issued on (None: the compute stream) -- data parallel waits on it."""
+    return _rt(model).get("wgrad_side")
 
 
 def _block_backward(g, gtap, model, blk: Block, saved):
     """g: f32 [M, D] gradient w.r.t. the block output (overwritten with the input gradient and returned)."""
     bs, slab16, slab32, x, s1, s2 = saved
     _fill_weights(bs, blk, model._shadow, bs.B, bs.N, backward=True)
-    ws = _backward_workspace(model, bs, g.device)
+    side = _wgrad_stream(model, g.device)
+    par = 0
+    rt = _rt(model)
+    if side is not None:
+        par = rt["bwd_parity"] = 1 - rt["bwd_parity"]
+        done = rt["wgrad_done"][par]
+        if done is not None:                       # the weight gradients that last read this workspace (two blocks ago)
+            torch.cuda.current_stream().wait_event(done)
+    ws = _backward_workspace(model, bs, g.device, par)
     gr = ffi.BlockGrads()
     ffi.check(ffi.lib().dkd_block_bwd_workspace_carve(ws.data_ptr(), bs.B, bs.N, bs.D, bs.hidden, ffi.C.byref(gr)), "bwd_workspace")
     gr.g, gr.gtap = g.data_ptr(), ffi.ptr(gtap)
+    gr.defer_wgrad = 1 if side is not None else 0
     a, m = blk.attn, blk.mlp
     gr.d_ln1_w, gr.d_ln1_b = ensure_grad(blk.norm1.weight).data_ptr(), ensure_grad(blk.norm1.bias).data_ptr()
     gr.d_ln2_w, gr.d_ln2_b = ensure_grad(blk.norm2.weight).data_ptr(), ensure_grad(blk.norm2.bias).data_ptr()
@@ -346,6 +390,22 @@ def _block_backward(g, gtap, model, blk: Block, saved):
     gr.d_fc1_w, gr.d_fc1_b = ensure_grad(m.fc1.weight).data_ptr(), ensure_grad(m.fc1.bias).data_ptr()
     gr.d_fc2_w, gr.d_fc2_b = ensure_grad(m.fc2.weight).data_ptr(), ensure_grad(m.fc2.bias).data_ptr()
     ffi.check(ffi.lib().dkd_block_bwd(ffi.C.byref(bs), ffi.C.byref(gr), ffi.stream()), "block_bwd")
+    if side is not None:
+        M, D, Hd = bs.B * bs.N, bs.D, bs.hidden
+        probs = (ffi.TnProblem * 4)()
+        for q, (pa, pb, pc, pcs, n1, n2) in zip(probs, ((gr.dF, bs.h, gr.d_fc2_w, gr.d_fc2_b, D, Hd), (gr.dH, bs.y2, gr.d_fc1_w, gr.d_fc1_b, Hd, D),
+                                                        (gr.dF2, bs.o, gr.d_proj_w, gr.d_proj_b, D, D),
+                                                        (gr.dqkv, bs.y1, gr.d_qkv_w, gr.d_qkv_b, 3 * D, D))):
+            q.A, q.B, q.C, q.a_colsum, q.M, q.N1, q.N2, q.lda, q.ldb, q.ldc = pa, pb, pc, pcs, M, n1, n2, n1, n2, n2
+            q.amap = q.bmap = IDENT
+        cur = torch.cuda.current_stream()
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            ffi.check(ffi.lib().dkd_gemm_tn_group(ffi.C.cast(probs, ffi.C.c_void_p), 4, ffi.stream()), "block wgrad")
+            ev = rt["wgrad_events"][par]
+            ev.record(side)
+        rt["wgrad_done"][par] = ev
+        slab16.record_stream(side)             # h, y2, o, y1 are read there after this function's caller drops them
     return g
 
 
@@ -408,6 +468,9 @@ class _BlockFn(torch.autograd.Function):
             g = g.float()
         gin = _block_backward(g, gtap, ctx.model, ctx.model.blocks[ctx.idx], ctx.saved)
         ctx.saved = None
+        side = wgrad_stream_of(ctx.model)
+        if side is not None and ctx.idx == 0:       # last block of the backward walk: everything downstream (embedding backward,
+            torch.cuda.current_stream().wait_stream(side)   # optimizer) sees all weight gradients
         hook = getattr(ctx.model, "_grad_ready_hook", None)     # data parallel: this block's gradients are final
         if hook is not None:
             hook(ctx.idx)

@@ -199,6 +199,11 @@ int dkd_dropout_mse(const float* a, const float* t, const float* keep, float kee
  * the algorithmic FLOPs (2 M N K), the summed durations (ms) and the launch counts (arrays of 3).  Off by default. */
 int dkd_probe_begin(void);
 int dkd_probe_end(double* flops, double* ms, int32_t* launches);
+/* The same with more families (arrays of n <= 6; bytes may be NULL): 3 = one student block's backward (every launch of one
+ * dkd_block_bwd call under one event pair; FLOPs = 2x the block's forward, bytes = each tensor the pass must touch once),
+ * 4 = the fused loss kernels (bytes: read a, read t, write da), 5 = one student block's training forward.  Families 3 and 5 CONTAIN
+ * the NT-GEMM launches that families 0-2 time individually. */
+int dkd_probe_end_ex(int32_t n, double* flops, double* bytes, double* ms, int32_t* launches);
 
 /* ---------------------------------------------------------------- transformer block drivers (host-side launch sequences) */
 /* One pre-LN ViT block ([3P] timm Block: x = x + dp(attn(ln1 x)); x = x + dp(mlp(ln2 x))) as ONE call: the library issues the
@@ -226,6 +231,9 @@ typedef struct {
   void* dT;                          /* bf16 workspace [M, D]                                                            */
   float* ln_ws;                      /* f32 scratch, 2 * D * ceil(M / 64) floats, for the LayerNorm backward partial sums; or NULL */
   void* dF2;                         /* second bf16 [M, D] workspace or NULL: with it all four weight gradients are one launch   */
+  int32_t defer_wgrad;               /* 1 (needs dF2): do NOT launch the four weight gradients; the caller issues them itself (one
+                                        dkd_gemm_tn_group over dF/h, dH/y2, dF2/o, dqkv/y1) -- e.g. on another stream, so that this
+                                        latency-bound launch (f32 atomics of 384 partial tiles) overlaps the next block's backward */
 } DkdBlockGrads;
 
 int dkd_blocks_fwd(const DkdBlock* blocks, int32_t n_blocks, void* stream);

@@ -13,8 +13,6 @@
 //    read with ds_read_b64_tr_b16 (hardware transpose), so no transposed activation copy ever exists in HBM.
 //  * epilogue goes through LDS so that bias / GELU / residual / DropPath-scale / feature-tap traffic is 16-B coalesced.
 //  * blockIdx -> tile map is XCD-aware (each XCD's L2 sees a contiguous run of tiles sharing A panels).
-#include <mutex>
-#include <vector>
 #include "common.h"
 
 namespace {

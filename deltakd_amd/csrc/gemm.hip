@@ -18,6 +18,7 @@
 namespace {
 
 constexpr int BM = 128, BK = 64;
+__device__ uint4 dkd_zero16 = {0u, 0u, 0u, 0u};      // source of LDS-DMA granules that must read as zeros (edges, conv padding)
 constexpr int CS_LD = 132;  // f32 staging row stride (floats) of the wgrad kernel's atomic epilogue
 
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
@@ -34,6 +35,7 @@ __device__ __forceinline__ float epi_scalar(const DkdGemm& g, float v, int m, in
     v = gelu_erf(v);
   }
   if (g.epi & DKD_EPI_DGELU) v *= dgelu_erf(bf2f(((const bf16_t*)g.preact)[(size_t)m * g.ldp + n]));
+  if (g.epi & DKD_EPI_RELU_GATE) v = bf2f(((const bf16_t*)g.preact)[(size_t)m * g.ldp + n]) > 0.f ? v : 0.f;
   if (g.epi & DKD_EPI_RELU) v = fmaxf(v, 0.f);
   if (g.tap) {
     if (g.epi & DKD_EPI_TAP_F32) ((float*)g.tap)[(size_t)m * g.ldt + n] = v;
@@ -72,7 +74,7 @@ __device__ __forceinline__ EpiIn epi_prefetch(const DkdGemm& g, const int vec_ok
       in.r0 = *(const f32x4*)rp;
       in.r1 = *(const f32x4*)(rp + 4);
     }
-    if (g.epi & DKD_EPI_DGELU) in.pre = *(const uint4*)&((const bf16_t*)g.preact)[(size_t)m * g.ldp + n];
+    if (g.epi & (DKD_EPI_DGELU | DKD_EPI_RELU_GATE)) in.pre = *(const uint4*)&((const bf16_t*)g.preact)[(size_t)m * g.ldp + n];
   }
   return in;
 }
@@ -94,6 +96,11 @@ __device__ __forceinline__ void epi_finish(const DkdGemm& g, const int vec_ok, f
       const f32x8 p = unpack8(in.pre);
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] *= dgelu_erf(p[e]);
+    }
+    if (g.epi & DKD_EPI_RELU_GATE) {
+      const f32x8 p = unpack8(in.pre);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = p[e] > 0.f ? v[e] : 0.f;
     }
     if (g.epi & DKD_EPI_RELU) {
 #pragma unroll
@@ -256,7 +263,12 @@ __device__ __forceinline__ void nt_epilogue(const DkdGemm& g, const int vec_ok, 
   }
 }
 
-template <int BN, int FAST = 0>
+// CONV: implicit GEMM of a 3 x 3 / pad 1 convolution on the hw x hw token grid (MGD generation block, model/models.py:148-151):
+// A is the activation x [B * hw * hw, Cin] itself, K = 9 * Cin with k = tap * Cin + c (tap = ky * 3 + kx); the A row a lane sources for
+// output row m and K step kt is row m + (ky - 1) * hw + (kx - 1) when that pixel lies inside the image, else a page of zeros -- the
+// gather lives in the LDS-DMA source addressing, the [M, 9 Cin] im2col matrix is never written.  Cin % 64 == 0 (a 64-wide K step
+// stays inside one tap).
+template <int BN, int FAST = 0, bool CONV = false>
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const DkdGemm g, const int vec_ok) {
   constexpr int NJ = BN / 32;             // 16-col MFMA tiles per wave along N
   constexpr int A_BYTES = BM * 128;       // 16 KiB
@@ -276,6 +288,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const DkdGemm g, const 
   // per-lane source rows for the LDS-DMA staging: 1 KiB chunk = 8 rows x 128 B; lane -> (row = lane>>3, slot = lane&7)
   const bf16_t* arow[4];
   int aslot[4];
+  int apy[4], apx[4];                     // CONV: pixel of the lane's row
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
     const int r = w * 32 + c * 8 + (lane >> 3);
@@ -283,7 +296,13 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const DkdGemm g, const 
     m = m < g.M ? m : g.M - 1;
     arow[c] = (const bf16_t*)g.A + (size_t)map_row(g.amap, m) * g.lda;
     aslot[c] = ((lane & 7) ^ ((r >> 1) & 7)) * 8;
+    if (CONV) {
+      const int p = m % (g.conv_hw * g.conv_hw);
+      apy[c] = p / g.conv_hw;
+      apx[c] = p % g.conv_hw;
+    }
   }
+  const int conv_cin = CONV ? g.K / 9 : 0;
   constexpr int BCH = BN / 32;  // B chunks per wave (BN rows / 8 rows per chunk / 4 waves)
   const bf16_t* brow[BCH];
   int bslot[BCH];
@@ -300,9 +319,20 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const DkdGemm g, const 
     char* abase = smem + buf * BUF;
     char* bbase = abase + A_BYTES;
     const int k0 = kt * BK;
+    if (CONV) {
+      const int tap = k0 / conv_cin, c0 = k0 - tap * conv_cin;
+      const int dy = tap / 3 - 1, dx = tap % 3 - 1;
 #pragma unroll
-    for (int c = 0; c < 4; ++c)
-      __builtin_amdgcn_global_load_lds(GLB_PTR(arow[c] + k0 + aslot[c]), LDS_PTR(abase + (w * 32 + c * 8) * 128), 16, 0, 0);
+      for (int c = 0; c < 4; ++c) {
+        const bool ok = (unsigned)(apy[c] + dy) < (unsigned)g.conv_hw && (unsigned)(apx[c] + dx) < (unsigned)g.conv_hw;
+        const bf16_t* src = ok ? arow[c] + (long)(dy * g.conv_hw + dx) * g.lda + c0 + aslot[c] : (const bf16_t*)&dkd_zero16;
+        __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(abase + (w * 32 + c * 8) * 128), 16, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        __builtin_amdgcn_global_load_lds(GLB_PTR(arow[c] + k0 + aslot[c]), LDS_PTR(abase + (w * 32 + c * 8) * 128), 16, 0, 0);
+    }
 #pragma unroll
     for (int c = 0; c < BCH; ++c)
       __builtin_amdgcn_global_load_lds(GLB_PTR(brow[c] + k0 + bslot[c]), LDS_PTR(bbase + (w * (BN / 4) + c * 8) * 128), 16, 0, 0);
@@ -634,7 +664,9 @@ constexpr int TN_TILE = 64 * TN_LD;        // 18 KiB per operand tile
 __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, float* C,
                                                          int M, int N1, int N2, int lda, int ldb, int ldc, DkdRowMap amap,
                                                          DkdRowMap bmap, int kt_per_split, float* __restrict__ a_colsum,
-                                                         int upper_only) {
+                                                         int upper_only, int conv_hw = 0, int conv_dy = 0, int conv_dx = 0) {
+  // conv_hw > 0: weight gradient of one tap of a 3 x 3 / pad 1 convolution -- the B row paired with reduction index m is the
+  // input pixel m + dy * hw + dx when it lies inside the image, zeros otherwise (no im2col matrix)
   __shared__ __attribute__((aligned(16))) char smem[4 * TN_TILE];  // [buf][A|B] ; reused by the epilogue (33 KiB)
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -669,15 +701,24 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const bf16_t* __restric
       s16x8 va = {0, 0, 0, 0, 0, 0, 0, 0}, vb = {0, 0, 0, 0, 0, 0, 0, 0};
       if (m < M) {
         const bf16_t* pa = A + (size_t)map_row(amap, m) * lda + n1_0 + lcol;
-        const bf16_t* pb = B + (size_t)map_row(bmap, m) * ldb + n2_0 + lcol;
+        long brow = map_row(bmap, m);
+        bool b_ok = true;
+        if (conv_hw > 0) {
+          const int p = m % (conv_hw * conv_hw), y = p / conv_hw + conv_dy, x = p % conv_hw + conv_dx;
+          b_ok = (unsigned)y < (unsigned)conv_hw && (unsigned)x < (unsigned)conv_hw;
+          brow = m + conv_dy * conv_hw + conv_dx;
+        }
+        const bf16_t* pb = B + (size_t)brow * ldb + n2_0 + lcol;
         if (n1_0 + lcol + 8 <= N1) va = *(const s16x8*)pa;
         else
           for (int e = 0; e < 8; ++e)
             if (n1_0 + lcol + e < N1) va[e] = (short)pa[e];
-        if (n2_0 + lcol + 8 <= N2) vb = *(const s16x8*)pb;
-        else
-          for (int e = 0; e < 8; ++e)
-            if (n2_0 + lcol + e < N2) vb[e] = (short)pb[e];
+        if (b_ok) {
+          if (n2_0 + lcol + 8 <= N2) vb = *(const s16x8*)pb;
+          else
+            for (int e = 0; e < 8; ++e)
+              if (n2_0 + lcol + e < N2) vb[e] = (short)pb[e];
+        }
       }
       ra[c] = va;
       rb[c] = vb;
@@ -957,7 +998,6 @@ __global__ __launch_bounds__(256, 2) void gemm_tn192_kernel(const bf16_t* __rest
 //    address of the DMA and to the fragment read address.
 //  * rows past M and columns past N1 / N2 are sourced from a 16-byte page of zeros.
 //  * the fused bias gradient (column sums of dY) is one more MFMA per row tile against a fragment of ones.
-__device__ uint4 dkd_zero16 = {0u, 0u, 0u, 0u};
 
 constexpr int TND_A_ST = 32 * 256, TND_UNIT = TND_A_ST + 32 * 384, TND_RING = 4;
 constexpr int TND_SMEM = TND_RING * TND_UNIT;                                    // 80 KiB; the epilogue reuses 49 KiB of it
@@ -1217,6 +1257,19 @@ extern "C" int dkd_gemm_nt(const DkdGemm* gp, void* stream) {
   DKD_CHECK_ARG(!(g.epi & DKD_EPI_DGELU) || g.preact, "gemm_nt: DGELU without preact pointer");
   DKD_CHECK_ARG(!(g.epi & DKD_EPI_ACCUM) || (g.epi & DKD_EPI_OUT_F32), "gemm_nt: ACCUM needs f32 output");
   DKD_CHECK_ARG(!g.rowscale || g.rows_per_sample > 0, "gemm_nt: rowscale needs rows_per_sample");
+  DKD_CHECK_ARG(!(g.epi & DKD_EPI_RELU_GATE) || g.preact, "gemm_nt: RELU_GATE without the gate (preact) pointer");
+  if (g.conv_hw > 0) {
+    DKD_CHECK_ARG(g.K % 9 == 0 && (g.K / 9) % 64 == 0 && g.lda >= g.K / 9 && g.amap.rpg == 0 && g.M % (g.conv_hw * g.conv_hw) == 0,
+                  "gemm_nt(conv3x3): need K = 9 * Cin, Cin %% 64 == 0, identity A row map, M a multiple of hw^2 (K=%d M=%d hw=%d)", g.K, g.M,
+                  g.conv_hw);
+    int vec_ok_c = (g.N % 8 == 0) && (g.ldc % 8 == 0) && (((uintptr_t)g.C & 15) == 0);
+    if (g.epi & DKD_EPI_BIAS) vec_ok_c = vec_ok_c && (((uintptr_t)g.bias & 15) == 0);
+    if (g.preact) vec_ok_c = vec_ok_c && (g.ldp % 8 == 0) && (((uintptr_t)g.preact & 15) == 0);
+    DkdProbeScope probe(0, 2.0 * g.M * g.N * g.K, 0.0, as_stream(stream));
+    hipLaunchKernelGGL((gemm_nt_kernel<128, 0, true>), dim3(cdiv(g.M, BM) * cdiv(g.N, 128)), dim3(256), 0, as_stream(stream), g, vec_ok_c);
+    DKD_CHECK_LAUNCH("gemm_nt(conv3x3)");
+    return DKD_OK;
+  }
   int vec_ok = (g.N % 8 == 0) && (g.ldc % 8 == 0) && (((uintptr_t)g.C & 15) == 0);
   if (g.epi & DKD_EPI_BIAS) vec_ok = vec_ok && (((uintptr_t)g.bias & 15) == 0);
   if (g.epi & DKD_EPI_RESID) vec_ok = vec_ok && (g.ldr % 8 == 0) && (((uintptr_t)g.resid & 15) == 0);
@@ -1429,6 +1482,28 @@ extern "C" int dkd_gemm_tn(const void* A, const void* B, float* C, int32_t M, in
   hipLaunchKernelGGL(gemm_tn_kernel, dim3(tiles, splits), dim3(256), 0, as_stream(stream), (const bf16_t*)A, (const bf16_t*)B, C, M,
                      N1, N2, lda, ldb, ldc, amap, bmap, per, a_colsum, 0);
   DKD_CHECK_LAUNCH("gemm_tn");
+  return DKD_OK;
+}
+
+extern "C" int dkd_conv3x3_wgrad(const void* dY, const void* X, float* dW, float* dbias, int32_t B, int32_t hw, int32_t Cin, int32_t Cout,
+                                 void* stream) {
+  DKD_CHECK_ARG(dY && X && dW && B > 0 && hw > 0 && Cin > 0 && Cout > 0, "conv3x3_wgrad: bad arguments");
+  DKD_CHECK_ARG(Cin % 8 == 0 && Cout % 8 == 0, "conv3x3_wgrad: channel counts must be multiples of 8 (Cin=%d Cout=%d)", Cin, Cout);
+  DKD_CHECK_ARG(((uintptr_t)dY & 15) == 0 && ((uintptr_t)X & 15) == 0, "conv3x3_wgrad: operands must be 16-byte aligned");
+  const int M = B * hw * hw, KT = cdiv(M, 64);
+  const int tiles = cdiv(Cout, 128) * cdiv(Cin, 128);
+  int splits = 512 / tiles;
+  if (splits > cdiv(KT, 4)) splits = cdiv(KT, 4);
+  if (splits < 1) splits = 1;
+  const int per = cdiv(KT, splits);
+  splits = cdiv(KT, per);
+  const DkdRowMap id = {0, 0, 0};
+  for (int tap = 0; tap < 9; ++tap) {        // dW[o][tap][c] += sum_m dY[m][o] * X[m + shift(tap)][c]: one [Cout, Cin] block per tap
+    hipLaunchKernelGGL(gemm_tn_kernel, dim3(tiles, splits), dim3(256), 0, as_stream(stream), (const bf16_t*)dY, (const bf16_t*)X,
+                       dW + (size_t)tap * Cin, M, Cout, Cin, Cout, Cin, 9 * Cin, id, id, per, tap == 4 ? dbias : (float*)nullptr, 0, hw,
+                       tap / 3 - 1, tap % 3 - 1);
+    DKD_CHECK_LAUNCH("conv3x3_wgrad");
+  }
   return DKD_OK;
 }
 

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DKD_LIB") or os.path.join(_HERE, "lib", "libdkd.so")     # DKD_LIB: A/B another build of the same ABI
 
 EPI_BIAS, EPI_GELU, EPI_DGELU, EPI_RESID = 1, 2, 4, 8
-EPI_OUT_F32, EPI_TAP_F32, EPI_RELU, EPI_ACCUM = 16, 32, 64, 128
+EPI_OUT_F32, EPI_TAP_F32, EPI_RELU, EPI_ACCUM, EPI_RELU_GATE = 16, 32, 64, 128, 256
 
 
 class RowMap(C.Structure):
@@ -44,7 +44,7 @@ class Gemm(C.Structure):
         ("bias", C.c_void_p), ("resid", C.c_void_p), ("ldr", C.c_int32), ("rmap", RowMap),
         ("rowscale", C.c_void_p), ("rows_per_sample", C.c_int32),
         ("preact", C.c_void_p), ("ldp", C.c_int32),
-        ("tap", C.c_void_p), ("ldt", C.c_int32),
+        ("tap", C.c_void_p), ("ldt", C.c_int32), ("conv_hw", C.c_int32),
     ]
 
 
@@ -74,6 +74,7 @@ _SIGS = {
     "dkd_gemm_tn": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                               C.c_int32, RowMap, RowMap, C.c_void_p, C.c_void_p]),
     "dkd_gemm_tn_group": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
+    "dkd_conv3x3_wgrad": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "dkd_gram": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, RowMap, C.c_void_p]),
     "dkd_attn_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "dkd_attn_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,

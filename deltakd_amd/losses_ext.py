@@ -18,7 +18,12 @@ from .vit import BF16, F32, ensure_grad
 
 # ----------------------------------------------------------------------------------------------- MGD
 class _MgdFn(torch.autograd.Function):
-    """align -> where(mask, mask_token, .) -> Conv3x3 -> ReLU -> Conv3x3 -> masked MSE vs the teacher's last tap."""
+    """align -> where(mask, mask_token, .) -> Conv3x3 -> ReLU -> Conv3x3 -> masked MSE vs the teacher's last tap.
+
+    The two 3 x 3 convolutions (model/models.py:148-151) are implicit GEMMs: the activation [B*196, Dt] is the A operand as it is, the
+    kernel gathers the 3 x 3 neighbourhood (zero padding included) in its LDS-DMA source addressing, so the [B*196, 9 Dt] im2col
+    matrix -- 694 MB at Dt = 768, bs 256 -- is never written or read, forward or backward: the input gradient is the same convolution
+    applied to dY with flipped taps, the weight gradient nine split-M GEMMs against row-shifted views of the input."""
 
     @staticmethod
     def forward(ctx, tap, sm, align, t_tap, mask, scale, npre_s, npre_t):
@@ -31,37 +36,32 @@ class _MgdFn(torch.autograd.Function):
         c1, c2 = sm.generation[0], sm.generation[2]
         s = ops.gemm_nt(tap2, sh.get(align.weight), M=M, amap=strip_map(N, npre_s), bias=align.bias)
         xt = ops.mask_select(s, sm.mask_token.detach().reshape(-1).contiguous(), mask)
-        cols1 = ops.im2col3x3(xt, B, hw)
-        y1 = ops.gemm_nt(cols1, sh.get(c1.weight, conv3x3=True), bias=c1.bias, relu=True)
-        cols2 = ops.im2col3x3(y1, B, hw)
-        y2 = ops.gemm_nt(cols2, sh.get(c2.weight, conv3x3=True), bias=c2.bias, out_f32=True)
+        y1 = ops.gemm_nt(xt, sh.get(c1.weight, conv3x3=True), bias=c1.bias, relu=True, conv_hw=hw)
+        y2 = ops.gemm_nt(y1, sh.get(c2.weight, conv3x3=True), bias=c2.bias, out_f32=True, conv_hw=hw)
         loss = torch.zeros(1, device=tap.device, dtype=F32)
         Nt = t_tap.shape[1]
         dy2 = ops.mse_loss(y2, t_tap.reshape(B * Nt, Dt), loss, scale / (M * Dt), M=M, tmap=strip_map(Nt, npre_t), mask=mask)
-        ctx.sm, ctx.align, ctx.saved, ctx.dims = sm, align, (tap2, cols1, y1, cols2, dy2, mask), (B, N, Ds, npre_s, hw, M, Dt)
+        ctx.sm, ctx.align, ctx.saved, ctx.dims = sm, align, (tap2, xt, y1, dy2, mask), (B, N, Ds, npre_s, hw, M, Dt)
         return loss[0]
 
     @staticmethod
     def backward(ctx, g):
         sm, align = ctx.sm, ctx.align
         sh = sm._shadow
-        tap2, cols1, y1, cols2, dy2, mask = ctx.saved
+        tap2, xt, y1, dy2, mask = ctx.saved
         B, N, Ds, npre, hw, M, Dt = ctx.dims
         c1, c2 = sm.generation[0], sm.generation[2]
         dy2.mul_(g)
 
-        def conv_wgrad(dy, cols, conv):
+        def conv_wgrad(dy, x_in, conv):
             dwp = torch.zeros(Dt, 9 * Dt, device=dy.device, dtype=F32)
-            ops.gemm_tn(dy, cols, dwp)
+            ops.conv3x3_wgrad(dy, x_in, dwp, ensure_grad(conv.bias), B, hw)
             ensure_grad(conv.weight).add_(dwp.view(Dt, 3, 3, Dt).permute(0, 3, 1, 2))
-            ops.colsum(dy, ensure_grad(conv.bias))
 
-        conv_wgrad(dy2, cols2, c2)
-        dcols = ops.gemm_nt(dy2, sh.get(c2.weight, transposed=True, conv3x3=True))
-        dy1 = ops.col2im3x3(dcols, B, hw, relu_gate=y1)
-        conv_wgrad(dy1, cols1, c1)
-        dcols = ops.gemm_nt(dy1, sh.get(c1.weight, transposed=True, conv3x3=True))
-        dxt = ops.col2im3x3(dcols, B, hw)
+        conv_wgrad(dy2, y1, c2)
+        dy1 = ops.gemm_nt(dy2, sh.get(c2.weight, conv3x3="dgrad"), conv_hw=hw, relu_gate=y1)
+        conv_wgrad(dy1, xt, c1)
+        dxt = ops.gemm_nt(dy1, sh.get(c1.weight, conv3x3="dgrad"), conv_hw=hw)
         ds = ops.mask_select_bwd(dxt, mask, ensure_grad(sm.mask_token).view(-1))
         smap = strip_map(N, npre)
         ops.gemm_tn(ds, tap2, ensure_grad(align.weight), M=M, bmap=smap, colsum=ensure_grad(align.bias))

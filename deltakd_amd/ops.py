@@ -8,7 +8,7 @@ import ctypes as C
 import torch
 
 from . import ffi
-from .ffi import (EPI_ACCUM, EPI_BIAS, EPI_DGELU, EPI_GELU, EPI_OUT_F32, EPI_RELU, EPI_RESID, EPI_TAP_F32, IDENT, RowMap,
+from .ffi import (EPI_ACCUM, EPI_BIAS, EPI_DGELU, EPI_GELU, EPI_OUT_F32, EPI_RELU, EPI_RELU_GATE, EPI_RESID, EPI_TAP_F32, IDENT, RowMap,
                   check, lib, ptr, stream)
 
 BF16, F32 = torch.bfloat16, torch.float32
@@ -24,12 +24,17 @@ def _is_f32(t):
 
 def gemm_nt(a, b, out=None, *, M=None, bias=None, gelu=False, dgelu=False, relu=False, preact=None, resid=None, rowscale=None,
             rows_per_sample=0, tap=None, out_f32=False, accumulate=False, amap=IDENT, cmap=IDENT, rmap=IDENT, out_rows=None,
-            K=None, N=None):
+            K=None, N=None, conv_hw=0, relu_gate=None):
     """out[M, N] = epilogue(a[M, K] @ b[N, K]^T); a, b bf16 (2-D, row stride = stride(0)).
 
     ``M`` = logical rows (defaults to a.shape[0]; with ``amap`` the rows are gathered through the map).
     ``out_rows`` = rows of the allocated output when ``cmap`` scatters into a larger buffer.
+    ``conv_hw`` > 0: a is the activation [B * hw * hw, Cin] of a 3 x 3 / pad 1 convolution on the hw x hw token grid, b its weight as
+    [N, (ky, kx, cin)] (K = 9 Cin): implicit GEMM, the neighbourhood is gathered by the kernel (include/dkd.h, DkdGemm.conv_hw).
+    ``relu_gate`` (bf16 [M, N]): out = gate > 0 ? out : 0 -- the backward of a ReLU given its output.
     """
+    if conv_hw:
+        K = 9 * a.shape[1]
     assert a.dtype == BF16 and b.dtype == BF16 and a.dim() == 2 and b.dim() == 2
     assert a.stride(1) == 1 and b.stride(1) == 1
     M = a.shape[0] if M is None else M
@@ -55,6 +60,11 @@ def gemm_nt(a, b, out=None, *, M=None, bias=None, gelu=False, dgelu=False, relu=
         epi |= EPI_DGELU
     if relu:
         epi |= EPI_RELU
+    if relu_gate is not None:
+        assert preact is None and relu_gate.dtype == BF16
+        epi |= EPI_RELU_GATE
+        preact = relu_gate
+    g.conv_hw = conv_hw
     if preact is not None:
         assert preact.dtype == BF16
         g.preact, g.ldp = ptr(preact), preact.stride(0)
@@ -336,6 +346,16 @@ def col2im3x3(dcols, B, hw, relu_gate=None):
     dx = torch.empty(dcols.shape[0], Cc, device=dcols.device, dtype=BF16)
     check(lib().dkd_col2im3x3(ptr(dcols), ptr(relu_gate), ptr(dx), B, hw, Cc, stream()), "col2im3x3")
     return dx
+
+
+def conv3x3_wgrad(dy, x, dw, dbias, B, hw):
+    """dw f32 [Cout, 9 * Cin] (= [Cout, ky, kx, cin]) += weight gradient of the 3 x 3 / pad 1 convolution y = conv(x); dbias f32 [Cout] +=
+    column sums of dy.  dy bf16 [B*hw*hw, Cout], x bf16 [B*hw*hw, Cin]: no im2col matrix (include/dkd.h: dkd_conv3x3_wgrad)."""
+    assert dy.dtype == BF16 and x.dtype == BF16 and dy.is_contiguous() and x.is_contiguous() and dw.dtype == F32 and dw.is_contiguous()
+    Cout, Cin = dy.shape[1], x.shape[1]
+    assert dw.shape == (Cout, 9 * Cin) and dy.shape[0] == x.shape[0] == B * hw * hw
+    check(lib().dkd_conv3x3_wgrad(ptr(dy), ptr(x), ptr(dw), ptr(dbias), B, hw, Cin, Cout, stream()), "conv3x3_wgrad")
+    return dw
 
 
 def sort_l1_loss(s, t, loss, w, *, B, P, tmap=IDENT, grad_f32=False):

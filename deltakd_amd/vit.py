@@ -98,13 +98,18 @@ class Shadow:
             self._slots[k] = ((self.generation, p._version, p.data_ptr()), v[1], p)
 
     def get(self, p: torch.Tensor, transposed=False, pad_k_to=0, conv3x3=False):
-        """conv3x3: p is a [out, cin, 3, 3] conv weight, served as [out, (ky, kx, cin)] to match ops.im2col3x3's K order."""
+        """conv3x3: p is a [out, cin, 3, 3] conv weight, served as [out, (ky, kx, cin)] -- the K order of the implicit-GEMM convolution
+        (ops.gemm_nt conv_hw=) and of ops.im2col3x3.  conv3x3="dgrad": the operand of the INPUT gradient, the same convolution applied
+        to dY with the taps flipped and the channel roles swapped: [cin, (2 - ky, 2 - kx, out)]."""
         key = (id(p), transposed, pad_k_to, conv3x3)
         slot = self._slots.get(key)
         stamp = (self.generation, p._version, p.data_ptr())
         if slot is not None and slot[0] == stamp:
             return slot[1]
-        if conv3x3:
+        if conv3x3 == "dgrad":
+            assert not transposed
+            w2 = p.detach().flip(2, 3).permute(1, 2, 3, 0).reshape(p.shape[1], -1).contiguous()
+        elif conv3x3:
             w2 = p.detach().permute(0, 2, 3, 1).reshape(p.shape[0], -1).contiguous()
         else:
             w2 = p.detach().reshape(p.shape[0], -1)

@@ -48,7 +48,8 @@ enum {
   DKD_EPI_OUT_F32     = 1 << 4,  /* C is float (default: bf16)                               */
   DKD_EPI_TAP_F32     = 1 << 5,  /* tap (value before RESID) stored as float (default bf16)   */
   DKD_EPI_RELU        = 1 << 6,  /* v = max(v, 0)                                            */
-  DKD_EPI_ACCUM       = 1 << 7   /* C += v (f32 output only)                                  */
+  DKD_EPI_ACCUM       = 1 << 7,  /* C += v (f32 output only)                                  */
+  DKD_EPI_RELU_GATE   = 1 << 8   /* v = preact[m,n] > 0 ? v : 0  (backward of a ReLU whose OUTPUT is given as `preact`) */
 };
 
 typedef struct {
@@ -70,6 +71,11 @@ typedef struct {
   void* tap;          /* optional copy of (acc + bias) before RESID (the feature tap of
                          model/models.py:189-191), row stride ldt, rows = m                   */
   int32_t ldt;
+  int32_t conv_hw;    /* > 0: implicit GEMM of a 3 x 3 / pad 1 convolution on the hw x hw token grid (MGD generation block,
+                         model/models.py:148-151, model/loss.py:443-446): A is the activation x bf16 [B * hw * hw, Cin] (lda >= Cin),
+                         K = 9 * Cin, B the weight as [N, (ky, kx, cin)]; the 3 x 3 neighbourhood is gathered by the kernel's
+                         source addressing (zero padding included), no [M, 9 Cin] matrix exists.  The input gradient is the same
+                         call on dY with the weight flipped and transposed ([Cin, (2 - ky, 2 - kx, cout)]).  Cin % 64 == 0. */
 } DkdGemm;
 
 /* C[M,N] = epilogue(A[M,K] * B[N,K]^T).  Replaces nn.Linear / Conv2d-as-GEMM forward and the dgrad GEMMs
@@ -82,6 +88,13 @@ int dkd_gemm_nt(const DkdGemm* g, void* stream);
  * a_colsum (optional, f32 [N1]) += sum_m A[m, :]: the bias gradient, fused (A = dY is already streaming through LDS). */
 int dkd_gemm_tn(const void* A, const void* B, float* C, int32_t M, int32_t N1, int32_t N2, int32_t lda, int32_t ldb,
                 int32_t ldc, DkdRowMap amap, DkdRowMap bmap, float* a_colsum, void* stream);
+
+/* Weight (and bias) gradient of that convolution without an im2col matrix: dW f32 [Cout, 3, 3, Cin] (i.e. [Cout, (ky, kx, cin)], the
+ * layout the forward consumes) += sum_m dY[m, o] * x[m + (ky-1) hw + (kx-1), c] over the pixels whose neighbour lies inside the image;
+ * dbias f32 [Cout] += column sums of dY (may be NULL).  dY bf16 [B*hw*hw, Cout], x bf16 [B*hw*hw, Cin], both contiguous.
+ * Nine launches of the split-M TN kernel, one [Cout, Cin] block per tap. */
+int dkd_conv3x3_wgrad(const void* dY, const void* x, float* dW, float* dbias, int32_t B, int32_t hw, int32_t Cin, int32_t Cout,
+                      void* stream);
 
 /* Upper triangle (128 x 128 tile granularity) of the Gram matrix C[N,N] += A[M,N]^T A[M,N]: the tiles below the diagonal are not
  * touched -- the caller mirrors them (LRKD: G = T^T T of the teacher feature matrix, model/loss.py:318-321; 21 of 36 tiles for

@@ -346,38 +346,38 @@ def test_real_architecture_step_matches_oracle(kind):
 
 
 def test_generation_conv_as_gemm_full_size(ops):
-    """MGD's Conv3x3(768, 768) at the headline shape (B = 256: M = 50 176 rows, K = 9 * 768 = 6 912), forward, dgrad and wgrad, by
-    slices against torch's fp32 conv2d on whole images (first, middle, last)."""
+    """MGD's Conv3x3(768, 768) at the headline shape (B = 256: M = 50 176 rows, K = 9 * 768 = 6 912) as implicit GEMMs (no im2col
+    matrix): forward, input gradient and weight gradient, by slices against torch's fp32 conv2d on whole images (first, middle, last)."""
     Bc, hw, Cc = 256, 14, 768
     xg = rnd(Bc * hw * hw, Cc, seed=31).to(BF16)
     w = rnd(Cc, Cc, 3, 3, scale=0.02, seed=32)
     bias = rnd(Cc, seed=33)
-    w2 = w.permute(0, 2, 3, 1).reshape(Cc, 9 * Cc).contiguous().to(BF16)            # [out, (ky, kx, cin)]
-    cols = ops.im2col3x3(xg, Bc, hw)
-    y = ops.gemm_nt(cols, w2, bias=bias, relu=True)
+    wf = w.permute(0, 2, 3, 1).reshape(Cc, 9 * Cc).contiguous().to(BF16)            # [out, (ky, kx, cin)]
+    wd = w.flip(2, 3).permute(1, 2, 3, 0).reshape(Cc, 9 * Cc).contiguous().to(BF16)  # [cin, (2-ky, 2-kx, out)]
+    y = ops.gemm_nt(xg, wf, bias=bias, relu=True, conv_hw=hw)
     imgs = (0, 131, Bc - 1)
     P = hw * hw
+    wq = w.to(BF16).float()
 
     def conv_ref(b):
         xi = xg[b * P:(b + 1) * P].float().t().reshape(1, Cc, hw, hw)
-        return torch.nn.functional.conv2d(xi, w.to(BF16).float(), bias, padding=1).reshape(Cc, P).t()
+        return torch.nn.functional.conv2d(xi, wq, bias, padding=1).reshape(Cc, P).t()
     for b in imgs:
         assert rel(y[b * P:(b + 1) * P], torch.relu(conv_ref(b))) < 1e-2, ("fwd", b)
-    # dgrad: dcols = dy W2 -> col2im
     dy = rnd(Bc * P, Cc, seed=34).to(BF16)
-    wt = w2.t().contiguous()                                                        # [9 C, out]
-    dcols = ops.gemm_nt(dy, wt)
-    dx = ops.col2im3x3(dcols, Bc, hw)
+    dx = ops.gemm_nt(dy, wd, conv_hw=hw)
     for b in imgs:
         dyi = dy[b * P:(b + 1) * P].float().t().reshape(1, Cc, hw, hw)
-        ref = torch.nn.functional.conv_transpose2d(dyi, w.to(BF16).float(), padding=1).reshape(Cc, P).t()
+        ref = torch.nn.functional.conv_transpose2d(dyi, wq, padding=1).reshape(Cc, P).t()
         assert rel(dx[b * P:(b + 1) * P], ref) < 1.5e-2, ("dgrad", b)
-    # wgrad on a 16-image slab (the full-M reduction is covered by the wgrad tests above; K order is what matters here)
-    nb = 16
+    # weight gradient over all 50 176 rows against torch on 32-image slabs accumulated in fp64
     dwp = torch.zeros(Cc, 9 * Cc, device=DEV)
-    ops.gemm_tn(dy[:nb * P], cols[:nb * P], dwp)
-    xi = xg[:nb * P].float().reshape(nb, P, Cc).transpose(1, 2).reshape(nb, Cc, hw, hw)
-    dyi = dy[:nb * P].float().reshape(nb, P, Cc).transpose(1, 2).reshape(nb, Cc, hw, hw)
-    ref_dw = torch.nn.grad.conv2d_weight(xi, w.shape, dyi, padding=1)              # [out, cin, 3, 3]
-    got = dwp.view(Cc, 3, 3, Cc).permute(0, 3, 1, 2)
-    assert rel(got, ref_dw) < 1e-3
+    db = torch.zeros(Cc, device=DEV)
+    ops.conv3x3_wgrad(dy, xg, dwp, db, Bc, hw)
+    ref_dw = torch.zeros(Cc, Cc, 3, 3, device=DEV, dtype=torch.float64)
+    for b0 in range(0, Bc, 32):
+        xi = xg[b0 * P:(b0 + 32) * P].float().reshape(32, P, Cc).transpose(1, 2).reshape(32, Cc, hw, hw)
+        dyi = dy[b0 * P:(b0 + 32) * P].float().reshape(32, P, Cc).transpose(1, 2).reshape(32, Cc, hw, hw)
+        ref_dw += torch.nn.grad.conv2d_weight(xi, w.shape, dyi, padding=1).double()
+    assert rel(dwp.view(Cc, 3, 3, Cc).permute(0, 3, 1, 2), ref_dw.float()) < 1e-3
+    assert rel(db, dy.float().sum(0)) < 1e-4

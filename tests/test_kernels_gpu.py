@@ -500,6 +500,43 @@ def test_conv3x3_as_gather_gemm(ops):
     close(dxg, xi.grad.permute(0, 2, 3, 1).reshape(-1, C) * (gate.float() > 0), 2e-2, "conv dgrad relu")
 
 
+@pytest.mark.parametrize("B,hw,Cin,Cout", [(3, 4, 64, 64), (2, 14, 128, 192), (5, 7, 192, 64), (1, 14, 768, 768)])
+def test_conv3x3_implicit_gemm(ops, B, hw, Cin, Cout):
+    """Conv2d(Cin, Cout, 3, padding=1) on the token grid WITHOUT an im2col matrix (DkdGemm.conv_hw, dkd_conv3x3_wgrad): forward with
+    bias (+ReLU), input gradient (the same implicit GEMM on dY with flipped taps, + ReLU gate), weight and bias gradients, against
+    torch's fp32 conv2d autograd on the bf16-rounded operands."""
+    import torch.nn.functional as F
+    P = hw * hw
+    x = rnd(B * P, Cin, seed=110).to(BF16)
+    w = rnd(Cout, Cin, 3, 3, scale=0.1, seed=111)
+    bias = rnd(Cout, seed=112)
+    wf = w.permute(0, 2, 3, 1).reshape(Cout, 9 * Cin).contiguous().to(BF16)                    # [out, (ky, kx, cin)]
+    wd = w.flip(2, 3).permute(1, 2, 3, 0).reshape(Cin, 9 * Cout).contiguous().to(BF16)         # [cin, (2-ky, 2-kx, out)]
+    xi = x.float().view(B, hw, hw, Cin).permute(0, 3, 1, 2).requires_grad_(True)
+    wq = w.to(BF16).float().requires_grad_(True)
+    bq = bias.clone().requires_grad_(True)
+    ref = F.conv2d(xi, wq, bq, padding=1)
+    tok = lambda t: t.permute(0, 2, 3, 1).reshape(-1, t.shape[1])
+    y = ops.gemm_nt(x, wf, bias=bias, out_f32=True, conv_hw=hw)
+    close(y, tok(ref), 2e-5 * math.sqrt(9 * Cin) * 4, "conv fwd")
+    yr = ops.gemm_nt(x, wf, bias=bias, relu=True, conv_hw=hw)
+    close(yr, torch.relu(tok(ref)), 1e-2, "conv fwd relu (bf16 out)")
+    dy = rnd(B * P, Cout, seed=113).to(BF16)
+    ref.backward(dy.float().view(B, hw, hw, Cout).permute(0, 3, 1, 2))
+    dx = ops.gemm_nt(dy, wd, out_f32=True, conv_hw=hw)
+    close(dx, tok(xi.grad), 2e-5 * math.sqrt(9 * Cout) * 4, "conv dgrad")
+    gate = rnd(B * P, Cin, seed=114).to(BF16)
+    dxg = ops.gemm_nt(dy, wd, conv_hw=hw, relu_gate=gate)
+    close(dxg, tok(xi.grad) * (gate.float() > 0), 1e-2, "conv dgrad with relu gate")
+    dw = torch.zeros(Cout, 9 * Cin, device=dev())
+    db = torch.zeros(Cout, device=dev())
+    ops.conv3x3_wgrad(dy, x, dw, db, B, hw)
+    close(dw.view(Cout, 3, 3, Cin).permute(0, 3, 1, 2), wq.grad, 1e-4, "conv wgrad")
+    close(db, bq.grad, 1e-4, "conv bias grad")
+    ops.conv3x3_wgrad(dy, x, dw, None, B, hw)                                                   # accumulates
+    close(dw.view(Cout, 3, 3, Cin).permute(0, 3, 1, 2), 2 * wq.grad, 1e-4, "conv wgrad accumulates")
+
+
 @pytest.mark.parametrize("B,P,D", [(2, 16, 128), (3, 196, 192), (2, 49, 100)])
 def test_sort_l1(ops, B, P, D):
     from deltakd_amd.ffi import strip_map

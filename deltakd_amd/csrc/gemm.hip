@@ -665,8 +665,15 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const bf16_t* __restric
                                                          int M, int N1, int N2, int lda, int ldb, int ldc, DkdRowMap amap,
                                                          DkdRowMap bmap, int kt_per_split, float* __restrict__ a_colsum,
                                                          int upper_only, int conv_hw = 0, int conv_dy = 0, int conv_dx = 0) {
-  // conv_hw > 0: weight gradient of one tap of a 3 x 3 / pad 1 convolution -- the B row paired with reduction index m is the
-  // input pixel m + dy * hw + dx when it lies inside the image, zeros otherwise (no im2col matrix)
+  // conv_hw > 0: weight gradient of a 3 x 3 / pad 1 convolution, tap = blockIdx.z -- the B row paired with reduction index m is the
+  // input pixel m + dy * hw + dx when it lies inside the image, zeros otherwise (no im2col matrix); the tap's [N1, N2] block of
+  // C = dW[N1][9][N2] starts at column tap * N2
+  if (conv_hw > 0) {
+    conv_dy = (int)blockIdx.z / 3 - 1;
+    conv_dx = (int)blockIdx.z % 3 - 1;
+    C += blockIdx.z * N2;
+    if (blockIdx.z != 4) a_colsum = nullptr;
+  }
   __shared__ __attribute__((aligned(16))) char smem[4 * TN_TILE];  // [buf][A|B] ; reused by the epilogue (33 KiB)
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1492,18 +1499,17 @@ extern "C" int dkd_conv3x3_wgrad(const void* dY, const void* X, float* dW, float
   DKD_CHECK_ARG(((uintptr_t)dY & 15) == 0 && ((uintptr_t)X & 15) == 0, "conv3x3_wgrad: operands must be 16-byte aligned");
   const int M = B * hw * hw, KT = cdiv(M, 64);
   const int tiles = cdiv(Cout, 128) * cdiv(Cin, 128);
-  int splits = 512 / tiles;
+  // dW[o][tap][c] += sum_m dY[m][o] * X[m + shift(tap)][c]: one [Cout, Cin] block per tap, the nine taps side by side in ONE launch
+  // (grid.z); ~1500 workgroups in all, so few M-splits (= few atomically added partial tiles) per tap
+  int splits = cdiv(1536, 9 * tiles);
   if (splits > cdiv(KT, 4)) splits = cdiv(KT, 4);
   if (splits < 1) splits = 1;
   const int per = cdiv(KT, splits);
   splits = cdiv(KT, per);
   const DkdRowMap id = {0, 0, 0};
-  for (int tap = 0; tap < 9; ++tap) {        // dW[o][tap][c] += sum_m dY[m][o] * X[m + shift(tap)][c]: one [Cout, Cin] block per tap
-    hipLaunchKernelGGL(gemm_tn_kernel, dim3(tiles, splits), dim3(256), 0, as_stream(stream), (const bf16_t*)dY, (const bf16_t*)X,
-                       dW + (size_t)tap * Cin, M, Cout, Cin, Cout, Cin, 9 * Cin, id, id, per, tap == 4 ? dbias : (float*)nullptr, 0, hw,
-                       tap / 3 - 1, tap % 3 - 1);
-    DKD_CHECK_LAUNCH("conv3x3_wgrad");
-  }
+  hipLaunchKernelGGL(gemm_tn_kernel, dim3(tiles, splits, 9), dim3(256), 0, as_stream(stream), (const bf16_t*)dY, (const bf16_t*)X, dW, M,
+                     Cout, Cin, Cout, Cin, 9 * Cin, id, id, per, dbias, 0, hw, 0, 0);
+  DKD_CHECK_LAUNCH("conv3x3_wgrad");
   return DKD_OK;
 }
 

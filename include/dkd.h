@@ -92,7 +92,7 @@ int dkd_gemm_tn(const void* A, const void* B, float* C, int32_t M, int32_t N1, i
 /* Weight (and bias) gradient of that convolution without an im2col matrix: dW f32 [Cout, 3, 3, Cin] (i.e. [Cout, (ky, kx, cin)], the
  * layout the forward consumes) += sum_m dY[m, o] * x[m + (ky-1) hw + (kx-1), c] over the pixels whose neighbour lies inside the image;
  * dbias f32 [Cout] += column sums of dY (may be NULL).  dY bf16 [B*hw*hw, Cout], x bf16 [B*hw*hw, Cin], both contiguous.
- * Nine launches of the split-M TN kernel, one [Cout, Cin] block per tap. */
+ * One launch of the split-M TN kernel, the nine taps ([Cout, Cin] blocks) side by side in grid.z. */
 int dkd_conv3x3_wgrad(const void* dY, const void* x, float* dW, float* dbias, int32_t B, int32_t hw, int32_t Cin, int32_t Cout,
                       void* stream);
 

@@ -63,7 +63,7 @@ def _pair(kind, real):
         t = vit.VisionTransformer(128, 12, 2, C, True, 0.0, **TOY)
         s = vit.VisionTransformer(64, 12, 1, C, kind in ("soft", "hard"), 0.1, **TOY)
     args = loss_ref.default_args(distillation_type=kind, dataset="imagenet-1k" if real else "cifar-10", mgd_alpha=2.0, mgd_mask_ratio=0.5,
-                                 alpha=0.5, tau=3.0, opt="adamw", lr=1e-3, weight_decay=0.05, opt_eps=1e-8, opt_betas=None, mixup=0.8,
+                                 alpha=0.5, tau=3.0, opt="adamw", lr=2e-4, weight_decay=0.05, opt_eps=1e-8, opt_betas=None, mixup=0.8,
                                  cutmix=1.0, smoothing=0.1, epochs=1, print_freq=1000, rank=1)
     loss_ref.attach_aux_ref(o_s, o_t, kind)
     attach_aux(s, t, kind, args)
@@ -82,7 +82,9 @@ def _pair(kind, real):
 def test_train_one_epoch_matches_the_oracle_loop(kind, real):
     """2 steps, B = 4, mixup/cutmix on (numpy draws replayed from the same seed), DropPath keep masks and masking noise injected
     per step.  Checked: per-step loss (1e-2), epoch averages of loss / acc1 / acc5 / lr as train_one_epoch returns them, the
-    gradients of the SECOND step (they depend on the first update: 8e-2 per tensor, relative to the tensor's own norm), and the weights
+    gradients of the SECOND step (they depend on the first update: 8e-2 per tensor, relative to the tensor's own norm; lr = 2e-4: the
+    first Adam step moves every element by ~lr whatever its gradient, so elements at the bf16 noise level move in random directions and
+    the second step's gradients inherit lr-proportional differences on top of the 6e-2 of a single step), and the weights
     after two AdamW steps through their update  w2 - w0  (direction cosine >= 0.9 per tensor: an Adam step is ~ lr * sign(g) early on, so
     elements whose gradient is at the bf16 noise level may flip; the cosine bounds how many)."""
     from oracle import engine_ref, loss_ref

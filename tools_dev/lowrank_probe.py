@@ -10,12 +10,13 @@ from deltakd_amd.losses import LowRankTargets
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 calls = int(sys.argv[2]) if len(sys.argv) > 2 else 6
 same = len(sys.argv) > 3 and sys.argv[3] == "same"
+sweeps = int(os.environ.get("RITZ_SWEEPS", "2"))
 dev = "cuda:0"
 torch.manual_seed(42)
 t = vit.create_model("deit_base_distilled_patch16_224", num_classes=1000).to(dev).eval()
 for p in t.parameters():
     p.requires_grad = False
-solver = LowRankTargets()
+solver = LowRankTargets(ritz_sweeps=sweeps)
 g = torch.Generator(device=dev).manual_seed(1)
 x0 = torch.randn(B, 3, 224, 224, device=dev, generator=g)
 for c in range(calls):
@@ -28,4 +29,10 @@ for c in range(calls):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) * 1e3
     info = ops.lowrank_info(solver._ws, 3, 768).cpu().tolist()
-    print(f"call {c}: {dt:7.2f} ms  sweeps (orth, ritz) per layer {info}  ritz[0,:3] {solver.ritz[0,:3].tolist()} ritz[0,60:66] {[round(v,1) for v in solver.ritz[0,60:66].tolist()]} ritz[0,90:] {[round(v,1) for v in solver.ritz[0,90:].tolist()]}", flush=True)
+    # quality vs the exact SVD of this batch (layer 0): captured rank-64 energy and worst singular-value error
+    T = taps[0][:, 2:].reshape(-1, 768).float()
+    S = torch.linalg.svdvals(T.double())
+    got = tg[0].double()
+    energy = (got ** 2).sum().item() / (S[:64] ** 2).sum().item()
+    sverr = ((got.norm(dim=0) - S[:64]).abs() / S[0]).max().item()
+    print(f"call {c}: {dt:7.2f} ms  energy {energy:.5f} sv_err {sverr:.2e}  sweeps (orth, ritz) per layer {info}  ritz[0,:3] {solver.ritz[0,:3].tolist()} ritz[0,60:66] {[round(v,1) for v in solver.ritz[0,60:66].tolist()]} ritz[0,90:] {[round(v,1) for v in solver.ritz[0,90:].tolist()]}", flush=True)

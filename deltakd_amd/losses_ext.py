@@ -166,7 +166,7 @@ def diffkd_loss(student_model, student_features, teacher_features, alpha, npre_s
         Nt, Dt = t_tap.shape[1], t_tap.shape[2]
         P = Nt - npre_t
         M = B * P
-        temb = dn.time_embed(t.float().view(-1, 1))                      # [B, Dt]; tiny: stays on torch autograd
+        temb = dn.time_embed(t.float().view(-1, 1))                      # [B, Dt]: two callable vit.Linear layers (MFMA GEMMs) around a torch GELU
         noise = injected["noise"][i].reshape(M, Dt).contiguous() if "noise" in injected else torch.randn(M, Dt, device=dev)
         if "drop" in injected:
             keep = injected["drop"][i].reshape(M, Dt).contiguous()

@@ -40,8 +40,8 @@ class DenoisingNetwork(nn.Module):
     def __init__(self, dims):
         super().__init__()
         self.net = nn.Sequential(Linear(dims, dims * 2), nn.GELU(), Linear(dims * 2, dims), nn.Dropout(0.1))
-        self.time_embed = nn.Sequential(nn.Linear(1, dims), nn.GELU(), nn.Linear(dims, dims))
-        for m in (self.net[0], self.net[2]):       # nn.Linear default init, as the reference's nn.Linear layers get
+        self.time_embed = nn.Sequential(Linear(1, dims), nn.GELU(), Linear(dims, dims))     # [B, 1] -> [B, dims]: callable (vit._LinearFn)
+        for m in (self.net[0], self.net[2], self.time_embed[0], self.time_embed[2]):       # nn.Linear default init, as the reference's layers get
             ref = nn.Linear(m.in_features, m.out_features)
             with torch.no_grad():
                 m.weight.copy_(ref.weight)

@@ -145,6 +145,17 @@ __device__ __forceinline__ void epi_finish(const DkdGemm& g, const int vec_ok, f
   }
 }
 
+#ifndef DKD_NT_C_A
+#define DKD_NT_C_A 1
+#define DKD_NT_C_B 4
+#endif
+// streaming (nontemporal) 16-byte store: the bf16 activations these epilogues write (qkv, fc1 pre-activation and GELU output, dgrad
+// results) are consumed by a LATER kernel, 16 lanes of a wave cover whole 128-byte lines of a row
+__device__ __forceinline__ void nt_store16(bf16_t* p, const uint4 v) {
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  __builtin_nontemporal_store(u32x4{v.x, v.y, v.z, v.w}, (u32x4*)p);
+}
+
 // ---- epilogue shared by the 128-row NT kernels: ONE pass through LDS (f32 [128][BN], unpadded: the accumulator-layout
 // ds_write_b32 is only 2-way per 32-lane group = free, the row reads are contiguous), then 16-B coalesced fused stores.
 // FAST 3: C(f32) = resid + acc + bias with identity row maps, no row scale (the teacher's proj / fc2; bf16 tap optional) -- compiled
@@ -194,7 +205,7 @@ __device__ __forceinline__ void nt_epilogue(const DkdGemm& g, const int vec_ok, 
           const f32x4 lo = *(const f32x4*)&cs[rl * BN + col8], hi = *(const f32x4*)&cs[rl * BN + col8 + 4];
           f32x8 v = f32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]} + b8;
           if (FAST == 4) {
-            *(uint4*)&((bf16_t*)g.preact)[(size_t)m * g.ldp + n] = pack8(v);
+            nt_store16((bf16_t*)g.preact + (size_t)m * g.ldp + n, pack8(v));
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = gelu_erf_fast(v[e]);
           }
@@ -203,7 +214,9 @@ __device__ __forceinline__ void nt_epilogue(const DkdGemm& g, const int vec_ok, 
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] *= dgelu_erf_fast(p[e]);
           }
-          *(uint4*)((bf16_t*)g.C + (size_t)m * g.ldc + n) = pack8(v);
+          // forward outputs (qkv, GELU output) stream; a backward result is read again by the very next kernels (dgrad GEMM + wgrad)
+          if (FAST == DKD_NT_C_A || FAST == DKD_NT_C_B) nt_store16((bf16_t*)g.C + (size_t)m * g.ldc + n, pack8(v));
+          else *(uint4*)((bf16_t*)g.C + (size_t)m * g.ldc + n) = pack8(v);
         }
       }
     }

@@ -53,7 +53,7 @@ def make_args(cfg, batch, epochs=1):
     return SimpleNamespace(**a)
 
 
-def cpu_baseline(cfg, batch=16, steps=6):
+def cpu_baseline(cfg, batch=8, steps=6):
     """The oracle (CPU restatement of the reference path, fp32, torch CPU threads) timed on this host."""
     from oracle import loss_ref, vit_ref
     torch.manual_seed(42)

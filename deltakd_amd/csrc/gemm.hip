@@ -1354,6 +1354,8 @@ extern "C" int dkd_gemm_nt(const DkdGemm* gp, void* stream) {
     if (fast == 1) hipLaunchKernelGGL((gemm_nt256_kernel<DKD_NT256_ABL, 16, 4, 1>), grid, dim3(512), 0, as_stream(stream), g, n_tiles);
     else if (fast == 2) hipLaunchKernelGGL((gemm_nt256_kernel<DKD_NT256_ABL, 16, 4, 2>), grid, dim3(512), 0, as_stream(stream), g, n_tiles);
     else if (plain16) hipLaunchKernelGGL((gemm_nt256_kernel<DKD_NT256_ABL, 16, 4, 0>), grid, dim3(512), 0, as_stream(stream), g, n_tiles);
+    // f32 residual epilogue on the wide path: N = 768 (teacher proj / fc2) when >= 3 batches go through the teacher in one call
+    else if (fast3w) hipLaunchKernelGGL((gemm_nt256_kernel<DKD_NT256_ABL, 0, 4, 3>), grid, dim3(512), 0, as_stream(stream), g, n_tiles);
     else hipLaunchKernelGGL((gemm_nt256_kernel<DKD_NT256_ABL, 0, 4, 0>), grid, dim3(512), 0, as_stream(stream), g, n_tiles);
     DKD_CHECK_LAUNCH("gemm_nt256");
     return DKD_OK;

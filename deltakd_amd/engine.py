@@ -6,6 +6,7 @@ semantics, statement for statement.  Differences, all hos
   * ``forward_with_features`` works through a data-parallel wrapper.
 The loop itself is model-agnostic: any nn.Module student/teacher and any criterion with the reference's call contract work.
 """
+import collections
 import os
 
 import torch
@@ -34,18 +35,32 @@ def train_one_epoch(student_model, teacher_model, train_loader, criterion, optim
             samples, targets = mixup_fn(samples, targets)
         return samples.to(device, non_blocking=True), targets.to(device, non_blocking=True), original_targets
 
-    # One batch of lookahead, so that a criterion with a ``prefetch`` hook (deltakd_amd.losses.DistillationLoss) can start the
-    # frozen teacher on batch t+1 while the student's backward of batch t runs.  Batches, mixup draws (numpy RNG) and the
-    # student's torch RNG draws keep their order, so the step computes what the statement-for-statement loop computes.
+    # Lookahead, so that a criterion with a ``prefetch`` hook (deltakd_amd.losses.DistillationLoss) can run the frozen teacher ahead of
+    # the student: the next ``prefetch_group`` batches are fetched together and handed to the hook as one group (one teacher call), and
+    # a new group is started as soon as the student begins to consume the previous one, so the teacher stream always has a group in
+    # flight under the student's work.  Batches, mixup draws (numpy RNG) and the student's torch RNG draws keep their order, so every
+    # step computes what the statement-for-statement loop computes.
     prefetch = getattr(criterion, "prefetch", None)
     if args.distillation_type.lower() == "none" or os.environ.get("DKD_NO_LOOKAHEAD"):
         prefetch = None                  # nothing to start early: keep the plain order (next batch fetched after the step)
+    group_size = max(1, int(getattr(criterion, "prefetch_group", 1))) if prefetch is not None else 1
     args.current_epoch = epoch
-    nxt = fetch()
-    if nxt is not None and prefetch is not None:
-        prefetch(nxt[0], args)
-    while nxt is not None:
-        samples, targets, original_targets = nxt
+    pending = collections.deque()        # fetched batches, in order; with a prefetch hook their teacher work has been started
+
+    def start_group():
+        group = []
+        while len(group) < group_size:
+            b = fetch()
+            if b is None:
+                break
+            group.append(b)
+        if group and prefetch is not None:
+            prefetch([b[0] for b in group] if group_size > 1 else group[0][0], args)
+        pending.extend(group)
+
+    start_group()
+    while pending:
+        samples, targets, original_targets = pending.popleft()
 
         # --amp only ever wrapped the student forward in the reference (tools/engine.py:23-34); the HIP path already computes
         # in bf16 with fp32 accumulation, so the flag changes nothing here.
@@ -57,10 +72,8 @@ def train_one_epoch(student_model, teacher_model, train_loader, criterion, optim
 
         loss = criterion(samples, student_logits, student_model, student_feats, targets, args)
 
-        if prefetch is not None:
-            nxt = fetch()
-            if nxt is not None:
-                prefetch(nxt[0], args)
+        if prefetch is not None and len(pending) < group_size:
+            start_group()                # between the loss and the backward: the teacher's next group overlaps the student's work
 
         if not isinstance(student_logits, torch.Tensor):
             student_logits, _ = student_logits
@@ -81,7 +94,7 @@ def train_one_epoch(student_model, teacher_model, train_loader, criterion, optim
         metric_logger.update(train_acc5=acc5.detach())
         metric_logger.update(train_lr=optimizer.param_groups[0]['lr'])
         if prefetch is None:
-            nxt = fetch()
+            start_group()
     return {k: meter.global_avg for k, meter in metric_logger.meters.items()}
 
 

@@ -15,6 +15,7 @@ What differs by design (MI355X-first):
   * prefix tokens stripped are each model's ``num_prefix_tokens`` (the reference hard-codes student 1 / teacher 2).
 """
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -276,8 +277,14 @@ def lrkd_loss(teacher_features, student_features, rank=10, alpha=0.1, beta=0.1, 
 
 # ----------------------------------------------------------------------------------------------- the criterion
 class DistillationLoss(nn.Module):
-    def __init__(self, base_criterion, teacher_model, distillation_type, alpha, tau, teacher_stream=None):
+    def __init__(self, base_criterion, teacher_model, distillation_type, alpha, tau, teacher_stream=None, prefetch_group=None):
         super().__init__()
+        # batches per teacher call when the step loop prefetches (deltakd_amd.engine).  With 3 x 256 images every teacher GEMM is a
+        # whole number of rounds of 256 x 256 tiles on 256 CUs (N = 768 at one batch: 594 tiles = 2.3 rounds) and the teacher takes
+        # 11.9 instead of 12.4 ms per 256 images (tools_dev/teacher_batch_probe.py) -- but the pipeline becomes bursty and its fill
+        # costs a whole group: measured 12.83k / 12.45k / 12.31k img/s for groups of 1 / 2 / 3 over 42 steps, so the default stays 1.
+        self.prefetch_group = prefetch_group if prefetch_group is not None else int(os.environ.get("DKD_PREFETCH_GROUP", "1"))
+        self._ahead = {}
         self.base_criterion = base_criterion
         self.teacher_model = teacher_model
         self.distillation_type = distillation_type
@@ -310,35 +317,56 @@ class DistillationLoss(nn.Module):
              "saliency_mgd": (-1,), "curkd": None}
 
     @torch.no_grad()
-    def run_teacher(self, inputs, kind, lrkd_rank=0):
-        """-> (logits, taps, lrkd_targets).  Everything no-grad that depends on the teacher only, i.e. what can run on the teacher
-        stream: the forward with its taps and, for lrkd, the low-rank targets."""
+    def run_teacher(self, inputs, kind, lrkd_rank=0, sizes=None):
+        """-> (logits, taps, lrkd_targets) -- or, with ``sizes`` (inputs = several consecutive batches concatenated), a list of such
+        triples, one per batch.  Everything no-grad that depends on the teacher only, i.e. what can run on the teacher stream: the
+        forward with its taps and, for lrkd, the low-rank targets (computed batch by batch, in order: the solver is warm-started)."""
         t = self.teacher_model
         if kind in ("soft", "hard"):
-            return t(inputs), None, None
+            logits = t(inputs)
+            if sizes is None:
+                return logits, None, None
+            return [(z, None, None) for z in torch.split(logits, sizes)]
         fwt = getattr(_unwrap(t), "forward_with_taps", None)
         if fwt is None:
             raise RuntimeError("teacher model has no forward_with_taps(); build it with deltakd_amd.vit.create_model")
         logits, taps = fwt(inputs, self._TAPS.get(kind))
-        tgt = None
-        if kind == "lrkd" and "lrkd_targets" not in self.injected:
-            pt = getattr(_unwrap(t), "num_prefix_tokens", 2)
-            tgt = self.lowrank([taps[0], taps[1], taps[11]], pt, lrkd_rank)
-        return logits, taps, tgt
+        pt = getattr(_unwrap(t), "num_prefix_tokens", 2)
+        want_tgt = kind == "lrkd" and "lrkd_targets" not in self.injected
+        if sizes is None:
+            tgt = self.lowrank([taps[0], taps[1], taps[11]], pt, lrkd_rank) if want_tgt else None
+            return logits, taps, tgt
+        out, lo = [], 0
+        for z, n in zip(torch.split(logits, sizes), sizes):
+            part = [None if tp is None else tp[lo:lo + n] for tp in taps]          # contiguous [n, N, D] slices of [sum, N, D]
+            tgt = self.lowrank([part[0], part[1], part[11]], pt, lrkd_rank) if want_tgt else None
+            out.append((z, part, tgt))
+            lo += n
+        return out
 
     def prefetch(self, inputs, args):
-        """Start the teacher's work for a batch ahead of the student's (deltakd_amd.engine calls this for batch t+1 between the
-        loss and the backward of batch t).  The teacher is frozen and draws no random numbers, so the results are those of the
-        in-order call; on the teacher stream its ~17 ms overlap the student's backward, optimizer step and next forward instead of
-        leaving the main stream idle.  ``forward`` picks the results up when it is given the same ``inputs`` object."""
+        """Start the teacher's work ahead of the student's (deltakd_amd.engine calls this between the loss and the backward of a
+        step).  ``inputs``: one batch, or a LIST of the next consecutive batches, which then go through the teacher in one call
+        (``prefetch_group``).  The teacher is frozen and draws no random numbers, so the results are those of the in-order calls; on the
+        teacher stream the work overlaps the student's backward, optimizer step and forward passes instead of leaving the main stream
+        idle.  ``forward`` picks a batch's results up when it is given the same ``inputs`` object (it waits on the group's event, not on
+        the stream: the next group may already be queued behind it)."""
         kind = self.distillation_type.lower()
-        if kind == "none" or self.teacher_stream is None or not inputs.is_cuda:
+        group = list(inputs) if isinstance(inputs, (list, tuple)) else [inputs]
+        if kind == "none" or self.teacher_stream is None or not group or not group[0].is_cuda:
             return
         st = self.teacher_stream
-        st.wait_stream(torch.cuda.current_stream())     # the batch (mixup) is ready; the previous batch's loss has read its targets
+        st.wait_stream(torch.cuda.current_stream())     # the batches (mixup) are ready; earlier losses have read their targets
+        rank = getattr(args, "lrkd_rank", 0)
         with torch.cuda.stream(st):
-            res = self.run_teacher(inputs, kind, getattr(args, "lrkd_rank", 0))
-        self._ahead = (inputs, kind, res)
+            if len(group) == 1:
+                res = [self.run_teacher(group[0], kind, rank)]
+            else:
+                res = self.run_teacher(torch.cat(group, 0), kind, rank, sizes=[x.shape[0] for x in group])
+            ev = torch.cuda.Event()
+            ev.record(st)
+        for x, r in zip(group, res):
+            self._ahead[id(x)] = (x, kind, r, ev)
 
     def _base(self, outputs, labels, w_base, kd_mode=0, z_kd=None, z_t=None, w_kd=0.0):
         """w_base * base criterion (+ w_kd * logit distillation, same launch); records the two addends."""
@@ -371,10 +399,10 @@ class DistillationLoss(nn.Module):
             raise ValueError(f"Invalid distillation type: {self.distillation_type}")
 
         rank = getattr(args, "lrkd_rank", 0)
-        ahead, self._ahead = getattr(self, "_ahead", None), None
+        ahead = self._ahead.pop(id(inputs), None)
         if ahead is not None and ahead[0] is inputs and ahead[1] == kind:
             t_logits, t_taps, lrkd_tgt = ahead[2]
-            torch.cuda.current_stream().wait_stream(self.teacher_stream)
+            torch.cuda.current_stream().wait_event(ahead[3])
         elif self.teacher_stream is not None:
             self.teacher_stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self.teacher_stream):

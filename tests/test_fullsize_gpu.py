@@ -69,6 +69,27 @@ def test_teacher_gemms_full_size(ops, name, N, K, epi):
         assert rel(out[sl], ref) < (1e-2 if out.dtype == BF16 else 1e-4), (name, lo)
 
 
+@pytest.mark.parametrize("name,K,tap", [("proj", 768, False), ("fc2", 3072, True)])
+def test_teacher_residual_gemms_three_batches_per_call(ops, name, K, tap):
+    """The teacher's N = 768 GEMMs when three batches go through it in one call (DistillationLoss.prefetch_group): M = 3 * 50 688 rows
+    are 1 782 tiles of 256 x 256 = 6.96 rounds, so the whole problem runs on the persistent kernel with the f32-residual epilogue
+    (a dispatch no other test reaches).  In-place residual (C aliases resid), as the inference path uses it."""
+    M, N = 3 * B * NT, 768
+    a = rnd(M, K, seed=41).to(BF16)
+    w = rnd(N, K, scale=0.05, seed=42).to(BF16)
+    bias = rnd(N, seed=43)
+    x = rnd(M, N, seed=44)
+    x0 = x.clone()
+    tp = torch.empty(M, N, device=DEV, dtype=BF16) if tap else None
+    out = ops.gemm_nt(a, w, out=x, bias=bias, resid=x, tap=tp)
+    assert out.data_ptr() == x.data_ptr()
+    for lo, hi in ((0, 300), (76000, 76300), (M - 333, M)):
+        ref = a[lo:hi].float() @ w.float().t() + bias
+        if tap:
+            assert rel(tp[lo:hi], ref) < 1e-2, (name, "tap", lo)
+        assert rel(x[lo:hi], ref + x0[lo:hi]) < 1e-4, (name, lo)
+
+
 @pytest.mark.parametrize("N1,N2", [(768, 192), (192, 768), (576, 192), (192, 192)])
 def test_student_wgrads_full_size(ops, N1, N2):
     M = B * NS_

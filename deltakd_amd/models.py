@@ -17,6 +17,15 @@ DATASET_NUM_CLASSES = {"cifar-100": 100, "cifar-10": 10, "imagenet-1k": 1000, "i
                        "caltech256": 256, "flowers": 102}     # dataset/datasets.py:10-46
 
 
+def _linear_default(i, o):
+    """Linear holder with nn.Linear's default (kaiming-uniform) init, as the reference's aux nn.Linear layers get."""
+    m, ref = Linear(i, o), nn.Linear(i, o)
+    with torch.no_grad():
+        m.weight.copy_(ref.weight)
+        m.bias.copy_(ref.bias)
+    return m
+
+
 class Conv3x3(nn.Module):
     """Parameter holder with nn.Conv2d(C, C, 3, padding=1)'s layout and default init (model/models.py:149-151)."""
 
@@ -49,13 +58,13 @@ class DenoisingNetwork(nn.Module):
 
 
 class SimpleAttention(nn.Module):
-    """model/models.py:38-56 (saliency scorer).  Only ever used to RANK tokens (argsort), so it carries no gradient; its small
-    [B*196, Dt] x [Dt, 2 Dt] projection and per-head softmax run as torch glue (rocBLAS), not as a libdkd kernel."""
+    """model/models.py:38-56 (saliency scorer).  Only ever used to RANK tokens (argsort), so it carries no gradient; the
+    [B*196, Dt] x [Dt, 2 Dt] projection is a callable vit.Linear (MFMA GEMM), the per-head softmax over 196 x 196 scores is torch glue."""
 
     def __init__(self, dim, num_heads=8):
         super().__init__()
         self.num_heads, self.scale = num_heads, (dim // num_heads) ** -0.5
-        self.qk = nn.Linear(dim, dim * 2, bias=True)
+        self.qk = _linear_default(dim, dim * 2)
 
     def forward(self, x):
         B, N, C = x.shape
@@ -70,8 +79,8 @@ class SimpleCrossAttention(nn.Module):
     def __init__(self, dim, num_heads=8):
         super().__init__()
         self.num_heads, self.scale = num_heads, (dim // num_heads) ** -0.5
-        self.q = nn.Linear(dim, dim, bias=True)
-        self.k = nn.Linear(dim, dim, bias=True)
+        self.q = _linear_default(dim, dim)
+        self.k = _linear_default(dim, dim)
 
     def forward(self, x_query, x_key):
         B, Nq, C = x_query.shape
@@ -79,15 +88,6 @@ class SimpleCrossAttention(nn.Module):
         q = self.q(x_query).reshape(B, Nq, self.num_heads, C // self.num_heads).permute(0, 2, 1, 3)
         k = self.k(x_key).reshape(B, Nk, self.num_heads, C // self.num_heads).permute(0, 2, 1, 3)
         return ((q @ k.transpose(-2, -1)) * self.scale).softmax(dim=-1).mean(dim=1)
-
-
-def _linear_default(i, o):
-    """Linear holder with nn.Linear's default (kaiming-uniform) init, as the reference's aux nn.Linear layers get."""
-    m, ref = Linear(i, o), nn.Linear(i, o)
-    with torch.no_grad():
-        m.weight.copy_(ref.weight)
-        m.bias.copy_(ref.bias)
-    return m
 
 
 def attach_aux(student, teacher, distillation_type, args=None):

@@ -300,13 +300,13 @@ __global__ __launch_bounds__(512, 1) void attn_fwd_ring_kernel(const bf16_t* __r
 
 // dQ: waves own query tiles; K (row + transposed reads) and V (row reads) in LDS.
 template <int NKT>
-__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out,
-                                                          const bf16_t* __restrict__ dout, const float* __restrict__ lse,
-                                                          bf16_t* __restrict__ dqkv, int N, int H) {
+__device__ __forceinline__ void attn_bwd_dq_body(const int bh, const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out,
+                                                 const bf16_t* __restrict__ dout, const float* __restrict__ lse,
+                                                 bf16_t* __restrict__ dqkv, int N, int H) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int i16 = lane & 15, fg = lane >> 4;
-  const int b = blockIdx.x / H, h = blockIdx.x % H;
+  const int b = bh / H, h = bh % H;
   const int D = H * 64, ld = 3 * D;
   const bf16_t* base = qkv + (size_t)b * N * ld + h * 64;
   char* Ks = smem;
@@ -379,13 +379,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
 
 // dK, dV: waves own key tiles; Q and dO (row + transposed reads), lse and delta in LDS.
 template <int NQT>
-__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out,
-                                                           const bf16_t* __restrict__ dout, const float* __restrict__ lse,
-                                                           bf16_t* __restrict__ dqkv, int N, int H) {
+__device__ __forceinline__ void attn_bwd_dkv_body(const int bh, const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out,
+                                                  const bf16_t* __restrict__ dout, const float* __restrict__ lse,
+                                                  bf16_t* __restrict__ dqkv, int N, int H) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int i16 = lane & 15, fg = lane >> 4;
-  const int b = blockIdx.x / H, h = blockIdx.x % H;
+  const int b = bh / H, h = bh % H;
   const int D = H * 64, ld = 3 * D;
   const bf16_t* base = qkv + (size_t)b * N * ld + h * 64;
   const bf16_t* obase = out + (size_t)b * N * D + h * 64;
@@ -473,6 +473,22 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __re
   }
 }
 
+// Both halves of the backward in ONE launch: 2 B H workgroups, two per CU.  Launched one after the other each half is 768 workgroups
+// on 512 slots = 1.5 rounds, i.e. two rounds of which the second is half empty; together they are exactly 3 rounds at DeiT-tiny's
+// 768 heads.  Blocks b and b + 8 (the same XCD under round-robin dispatch, so the same L2) are the two halves of one head: its
+// q, k, v, dO, O are fetched from HBM once.
+template <int NT>
+__global__ __launch_bounds__(256, 2) void attn_bwd_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out,
+                                                       const bf16_t* __restrict__ dout, const float* __restrict__ lse,
+                                                       bf16_t* __restrict__ dqkv, int N, int H, int n_heads) {
+  const int bid = blockIdx.x;
+  const int role = (bid >> 3) & 1;
+  const int bh = (bid >> 4) * 8 + (bid & 7);
+  if (bh >= n_heads) return;
+  if (role == 0) attn_bwd_dq_body<NT>(bh, qkv, out, dout, lse, dqkv, N, H);
+  else attn_bwd_dkv_body<NT>(bh, qkv, out, dout, lse, dqkv, N, H);
+}
+
 template <typename K>
 int set_smem(K kernel, int bytes) {
   if (bytes <= 65536) return 0;
@@ -543,13 +559,12 @@ extern "C" int dkd_attn_bwd(const void* qkv, const void* out, const void* dout, 
   const int nt = pick_tiles(N);
   const int smem1 = 2 * nt * 16 * KV_LD;
   const int smem2 = smem1 + 2 * nt * 16 * 4;
+  const int nbh = B * H;
+  const int grid = ((nbh + 7) / 8) * 16;           // groups of 16 blocks: 8 heads x {dQ half, dK/dV half}
   DISPATCH_NT(nt, {
-    if (int rc = set_smem(attn_bwd_dq_kernel<T>, smem1)) return rc;
-    if (int rc = set_smem(attn_bwd_dkv_kernel<T>, smem2)) return rc;
-    hipLaunchKernelGGL(attn_bwd_dq_kernel<T>, dim3(B * H), dim3(256), smem1, as_stream(stream), (const bf16_t*)qkv, (const bf16_t*)out,
-                       (const bf16_t*)dout, lse, (bf16_t*)dqkv, N, H);
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel<T>, dim3(B * H), dim3(256), smem2, as_stream(stream), (const bf16_t*)qkv, (const bf16_t*)out,
-                       (const bf16_t*)dout, lse, (bf16_t*)dqkv, N, H);
+    if (int rc = set_smem(attn_bwd_kernel<T>, smem2)) return rc;
+    hipLaunchKernelGGL(attn_bwd_kernel<T>, dim3(grid), dim3(256), smem2, as_stream(stream), (const bf16_t*)qkv, (const bf16_t*)out,
+                       (const bf16_t*)dout, lse, (bf16_t*)dqkv, N, H, nbh);
   });
   DKD_CHECK_LAUNCH("attn_bwd");
   return DKD_OK;

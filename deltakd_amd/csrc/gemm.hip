@@ -159,7 +159,8 @@ __device__ __forceinline__ void nt_store16(bf16_t* p, const uint4 v) {
 // ---- epilogue shared by the 128-row NT kernels: ONE pass through LDS (f32 [128][BN], unpadded: the accumulator-layout
 // ds_write_b32 is only 2-way per 32-lane group = free, the row reads are contiguous), then 16-B coalesced fused stores.
 // FAST 3: C(f32) = resid + acc + bias with identity row maps, no row scale (the teacher's proj / fc2; bf16 tap optional) -- compiled
-// without the generic path's per-vector flag tests and row-map arithmetic.  0: generic.
+// without the generic path's per-vector flag tests and row-map arithmetic.  7: C(f32) = resid + rowscale[sample] * (acc + bias), the
+// student's proj / fc2 under DropPath.  0: generic.
 template <int BN, int NJ, int FAST>
 __device__ __forceinline__ void nt_epilogue(const DkdGemm& g, const int vec_ok, char* smem, f32x4 (&acc)[4][NJ], const int m0,
                                             const int n0, const int tid, const int wr, const int wc) {
@@ -222,7 +223,7 @@ __device__ __forceinline__ void nt_epilogue(const DkdGemm& g, const int vec_ok, 
     }
     return;
   }
-  if (FAST == 3) {
+  if (FAST == 3 || FAST == 7) {           // 7: the same with the DropPath row scale (the student's proj / fc2)
     constexpr int SW = 64 / RPP;
     const f32x4 b0 = *(const f32x4*)&g.bias[n], b1 = *(const f32x4*)&g.bias[n + 4];
     const bool tap = g.tap != nullptr;
@@ -248,8 +249,14 @@ __device__ __forceinline__ void nt_epilogue(const DkdGemm& g, const int vec_ok, 
             *(uint4*)&((bf16_t*)g.tap)[(size_t)m * g.ldt + n] = uint4{pack2bf(lo[0], lo[1]), pack2bf(lo[2], lo[3]), pack2bf(hi[0], hi[1]),
                                                                        pack2bf(hi[2], hi[3])};
           float* cp = (float*)g.C + (size_t)m * g.ldc + n;
-          *(f32x4*)cp = r0v[s] + lo;
-          *(f32x4*)(cp + 4) = r1v[s] + hi;
+          if (FAST == 7) {
+            const float sc = g.rowscale[m / g.rows_per_sample];
+            *(f32x4*)cp = r0v[s] + sc * lo;
+            *(f32x4*)(cp + 4) = r1v[s] + sc * hi;
+          } else {
+            *(f32x4*)cp = r0v[s] + lo;
+            *(f32x4*)(cp + 4) = r1v[s] + hi;
+          }
         }
       }
     }
@@ -1370,8 +1377,11 @@ extern "C" int dkd_gemm_nt(const DkdGemm* gp, void* stream) {
     else if (g.epi == 0 && !g.preact) fast = 6;
   }
 #define NT_LAUNCH(BN_, F_) hipLaunchKernelGGL((gemm_nt_kernel<BN_, F_>), dim3(tiles_m * cdiv(g.N, BN_)), dim3(256), 0, as_stream(stream), g, vec_ok)
+  const bool fast7 = vec_ok && g.N % 8 == 0 && g.epi == (DKD_EPI_BIAS | DKD_EPI_RESID | DKD_EPI_OUT_F32) && g.rowscale && g.amap.rpg >= 0 &&
+                     g.cmap.rpg == 0 && g.rmap.rpg == 0 && !g.preact && !(g.tap && (g.epi & DKD_EPI_TAP_F32));
   if (narrow) {
-    if (fast == 1) NT_LAUNCH(64, 1);
+    if (fast7) NT_LAUNCH(64, 7);
+    else if (fast == 1) NT_LAUNCH(64, 1);
     else if (fast == 4) NT_LAUNCH(64, 4);
     else if (fast == 5) NT_LAUNCH(64, 5);
     else if (fast == 6) NT_LAUNCH(64, 6);
@@ -1380,6 +1390,7 @@ extern "C" int dkd_gemm_nt(const DkdGemm* gp, void* stream) {
     const bool fast3 = vec_ok && g.N % 128 == 0 && g.epi == (DKD_EPI_BIAS | DKD_EPI_RESID | DKD_EPI_OUT_F32) && !g.rowscale &&
                        g.cmap.rpg == 0 && g.rmap.rpg == 0 && !g.preact && !(g.tap && (g.epi & DKD_EPI_TAP_F32));
     if (fast3) NT_LAUNCH(128, 3);
+    else if (fast7 && g.N % 128 == 0) NT_LAUNCH(128, 7);
     else if (fast == 1) NT_LAUNCH(128, 1);
     else if (fast == 4) NT_LAUNCH(128, 4);
     else if (fast == 5) NT_LAUNCH(128, 5);

@@ -1,4 +1,5 @@
 // Host-side launch sequences for one transformer block (see include/dkd.h): the library, not Python, walks the kernels.
+#include <stdlib.h>
 #include "common.h"
 
 namespace {
@@ -84,12 +85,20 @@ extern "C" int dkd_block_bwd(const DkdBlock* bp, const DkdBlockGrads* gp, void* 
                                {r.dH, b.y2, r.d_fc1_w, r.d_fc1_b, M, Hd, D, Hd, D, D, ID, ID}};
     TRY(dkd_gemm_tn_group(w, 2, st));
   }
-  g = mk(r.dH, b.fc1_wt, r.dT, M, D, Hd);
-  TRY(dkd_gemm_nt(&g, st));
-  TRY(dkd_layernorm_bwd(r.dT, 0, b.x1, D, ID, b.ln2_w, b.mean2, b.rstd2, r.g, D, ID, 1, r.d_ln2_w, r.d_ln2_b, M, D, r.ln_ws, st));
-  // ---- attention branch
+  // D = 192 (the DeiT-tiny student): the dgrad GEMMs that end a branch carry the LayerNorm backward (and the scale-cast that opens
+  // the next branch) as their epilogue -- dT never goes to memory
+  const bool fuse_ln = D == 192 && Hd % 64 == 0 && r.ln_ws != nullptr && getenv("DKD_NO_LNBWD_FUSION") == nullptr;
   void* dFa = all4 ? r.dF2 : r.dF;      // gradient w.r.t. the attention branch's output (bf16)
-  TRY(dkd_scale_cast_bf16(r.g, D, ID, b.s1, b.N, nullptr, 1, 0, dFa, D, M, D, st));
+  if (fuse_ln) {
+    TRY(dkd_gemm_nt_lnbwd(r.dH, b.fc1_wt, M, Hd, Hd, Hd, b.x1, D, b.ln2_w, b.mean2, b.rstd2, r.g, D, r.d_ln2_w, r.d_ln2_b, r.ln_ws, dFa, b.s1,
+                          b.N, st));
+  } else {
+    g = mk(r.dH, b.fc1_wt, r.dT, M, D, Hd);
+    TRY(dkd_gemm_nt(&g, st));
+    TRY(dkd_layernorm_bwd(r.dT, 0, b.x1, D, ID, b.ln2_w, b.mean2, b.rstd2, r.g, D, ID, 1, r.d_ln2_w, r.d_ln2_b, M, D, r.ln_ws, st));
+    // ---- attention branch
+    TRY(dkd_scale_cast_bf16(r.g, D, ID, b.s1, b.N, nullptr, 1, 0, dFa, D, M, D, st));
+  }
   g = mk(dFa, b.proj_wt, r.dT, M, D, D);
   TRY(dkd_gemm_nt(&g, st));
   TRY(dkd_attn_bwd(b.qkv, b.o, r.dT, b.lse, r.dqkv, b.B, b.N, b.H, st));
@@ -105,6 +114,11 @@ extern "C" int dkd_block_bwd(const DkdBlock* bp, const DkdBlockGrads* gp, void* 
     const DkdTnProblem w[2] = {{dFa, b.o, r.d_proj_w, r.d_proj_b, M, D, D, D, D, D, ID, ID},
                                {r.dqkv, b.y1, r.d_qkv_w, r.d_qkv_b, M, 3 * D, D, 3 * D, D, D, ID, ID}};
     TRY(dkd_gemm_tn_group(w, 2, st));
+  }
+  if (fuse_ln) {
+    TRY(dkd_gemm_nt_lnbwd(r.dqkv, b.qkv_wt, M, 3 * D, 3 * D, 3 * D, b.x, D, b.ln1_w, b.mean1, b.rstd1, r.g, D, r.d_ln1_w, r.d_ln1_b, r.ln_ws,
+                          nullptr, nullptr, 0, st));
+    return DKD_OK;
   }
   g = mk(r.dqkv, b.qkv_wt, r.dT, M, D, 3 * D);
   TRY(dkd_gemm_nt(&g, st));

@@ -678,6 +678,219 @@ __global__ __launch_bounds__(128 * WN, WN == 4 ? 1 : 2) void gemm_nt256_kernel(c
   }
 }
 
+// ------------------------------------------------------------------------------------------------ dgrad GEMM + LayerNorm backward
+// The narrow student (D = 192): the dgrad GEMMs that end a branch -- dT = dH W1 (K = hidden) and dT = dqkv Wqkv (K = 3 D) -- have
+// N = D, so a 128 x 192 tile holds whole rows and the LayerNorm backward that consumes dT can BE the epilogue:
+//     dx = rstd (dT gamma - mean(dT gamma) - xhat mean(dT gamma xhat)),   g += dx,   dgamma += dT xhat,   dbeta += dT
+// dT never goes to memory (round trip of 2 x 19 MB and a launch per LayerNorm at bs 256), it stays f32 instead of being rounded to
+// bf16, and the scale-cast that opens the next branch (dF = bf16(rowscale g)) rides along as a second output.
+// Mainloop = gemm_nt_kernel's (LDS-DMA double buffering) on a 128 x 192 tile; LDS 2 x 40 KiB: two workgroups per CU.
+// Epilogue: the tile through LDS (f32 [64][196]), then the row pass of ln_bwd_kernel (16 lanes per row, 12 columns per lane) with the
+// per-column partial sums of dgamma / dbeta written to the workspace rows of ln_bwd_reduce_kernel.
+struct LnBwdEpi {
+  const float* x;          // f32 [M, ldx] input of the LayerNorm (forward)
+  const float* gamma;
+  const float* mean;
+  const float* rstd;
+  float* dx;               // f32 [M, lddx]: += LN'(dT)
+  float* part;             // f32 [gridDim.x][2 * 192] per-block partial sums (dgamma | dbeta)
+  bf16_t* cast_out;        // optional bf16 [M, 192]: rowscale[row / rows_per_sample] * (updated dx)
+  const float* rowscale;   // optional (NULL = 1)
+  int ldx, lddx, rows_per_sample;
+};
+constexpr int LNB_D = 192, LNB_CS = 196, LNB_BM = 128;
+__global__ __launch_bounds__(256, 2) void gemm_nt_lnbwd_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W, const int M,
+                                                            const int K, const int lda, const int ldb, const LnBwdEpi ln) {
+  // 128 x 192 tile, the four waves SIDE BY SIDE along N (wave tile 128 x 48: 8 x 3 MFMA tiles, 96 accumulator registers): every wave
+  // owns rows of every 32-row quarter of the epilogue, so the accumulators drain quarter by quarter and the global loads of the 8
+  // rows a wave normalises per quarter (x and the gradient rows: 48 registers) are in flight before the quarter is staged.  Measured on the
+  // way here: 2 x 2 waves on 128 rows -- no registers for that, the row pass was a chain of exposed round trips, 62 us = no faster
+  // than the three kernels it replaces; 64-row tiles -- W is streamed through the LDS-DMA path (~25 B/clk/CU) once per 64 rows, 54 us.
+  constexpr int BN = LNB_D, NJ = 3;
+  constexpr int A_BYTES = LNB_BM * 128, B_BYTES = BN * 128, BUF = A_BYTES + B_BYTES;      // 16 + 24 KiB per stage
+  __shared__ __attribute__((aligned(16))) char smem[2 * BUF];      // 80 KiB; the epilogue uses 64 * 196 * 4 = 49 KiB of it
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int m0 = xcd_remap(blockIdx.x, gridDim.x) * LNB_BM;
+  const int KT = K / BK;
+
+  const bf16_t* arow[4];
+  int aslot[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const int r = w * 32 + c * 8 + (lane >> 3);
+    int m = m0 + r;
+    m = m < M ? m : M - 1;
+    arow[c] = A + (size_t)m * lda;
+    aslot[c] = ((lane & 7) ^ ((r >> 1) & 7)) * 8;
+  }
+  constexpr int BCH = BN / 32;                 // 6 chunks of 8 W rows per wave
+  const bf16_t* brow[BCH];
+  int bslot[BCH];
+#pragma unroll
+  for (int c = 0; c < BCH; ++c) {
+    const int r = w * (BN / 4) + c * 8 + (lane >> 3);
+    brow[c] = W + (size_t)r * ldb;
+    bslot[c] = ((lane & 7) ^ ((r >> 1) & 7)) * 8;
+  }
+  auto stage = [&](int kt, int buf) {
+    char* abase = smem + buf * BUF;
+    char* bbase = abase + A_BYTES;
+    const int k0 = kt * BK;
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+      __builtin_amdgcn_global_load_lds(GLB_PTR(arow[c] + k0 + aslot[c]), LDS_PTR(abase + (w * 32 + c * 8) * 128), 16, 0, 0);
+#pragma unroll
+    for (int c = 0; c < BCH; ++c)
+      __builtin_amdgcn_global_load_lds(GLB_PTR(brow[c] + k0 + bslot[c]), LDS_PTR(bbase + (w * (BN / 4) + c * 8) * 128), 16, 0, 0);
+  };
+
+  f32x4 acc[8][NJ];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int frow = lane & 15, fg = lane >> 4, fswz = (frow >> 1) & 7;
+
+  stage(0, 0);
+  for (int kt = 0; kt < KT; ++kt) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (kt + 1 < KT) stage(kt + 1, (kt + 1) & 1);
+    const char* abase = smem + (kt & 1) * BUF;
+    const char* bbase = abase + A_BYTES;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const int ps = ((kk * 4 + fg) ^ fswz) * 16;
+      bf16x8 b[NJ];
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) b[j] = *(const bf16x8*)(bbase + (w * (BN / 4) + j * 16 + frow) * 128 + ps);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const bf16x8 a = *(const bf16x8*)(abase + (i * 16 + frow) * 128 + ps);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b[j], acc[i][j], 0, 0, 0);
+      }
+    }
+  }
+
+  // ---- epilogue: LayerNorm backward on whole rows, 32 rows at a time (f32 [32][196] through LDS).  16 lanes per row (lane owns
+  // float4 columns sl, sl + 16, sl + 32).
+  const int sl = lane & 15, gq = lane >> 4;
+  float* cs = (float*)smem;
+  f32x4 gam[3], ag[3], ab[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    gam[i] = *(const f32x4*)(ln.gamma + 4 * (sl + 16 * i));
+    ag[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    ab[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {                // 32 rows at a time: a wave owns 8 of them = 2 passes of 4 rows
+    // x, the gradient rows and the statistics of the wave's 8 rows are requested before the quarter is staged
+    f32x4 xv[2][3], dv[2][3];
+    float mus[2], rss[2];
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int row = m0 + q * 32 + w * 8 + it * 4 + gq;
+      const bool live = row < M;
+      const float* xr = ln.x + (size_t)(live ? row : 0) * ln.ldx;
+      const float* dr = ln.dx + (size_t)(live ? row : 0) * ln.lddx;
+      mus[it] = live ? ln.mean[row] : 0.f;
+      rss[it] = live ? ln.rstd[row] : 0.f;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        xv[it][i] = *(const f32x4*)(xr + 4 * (sl + 16 * i));
+        dv[it][i] = *(const f32x4*)(dr + 4 * (sl + 16 * i));
+      }
+    }
+    __syncthreads();                           // the K loop's last fragment reads / the previous quarter's row pass are done
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) cs[(i * 16 + fg * 4 + r) * LNB_CS + w * (BN / 4) + j * 16 + frow] = acc[q * 2 + i][j][r];
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int rl = w * 8 + it * 4 + gq;
+      const int row = m0 + q * 32 + rl;
+      const bool live = row < M;
+      const float mu = mus[it], rs = rss[it];
+      f32x4 xh[3], gy[3];
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        const int c4 = 4 * (sl + 16 * i);
+        xh[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        gy[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (live) {
+          const f32x4 d = *(const f32x4*)&cs[rl * LNB_CS + c4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            xh[i][e] = (xv[it][i][e] - mu) * rs;
+            ab[i][e] += d[e];
+            ag[i][e] += d[e] * xh[i][e];
+            gy[i][e] = d[e] * gam[i][e];
+            s1 += gy[i][e];
+            s2 += gy[i][e] * xh[i][e];
+          }
+        }
+      }
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) {
+        s1 += __shfl_xor(s1, o, 64);
+        s2 += __shfl_xor(s2, o, 64);
+      }
+      s1 *= 1.f / LNB_D;
+      s2 *= 1.f / LNB_D;
+      if (live) {
+        float* dr = ln.dx + (size_t)row * ln.lddx;
+        const float sc = ln.cast_out ? (ln.rowscale ? ln.rowscale[row / ln.rows_per_sample] : 1.f) : 0.f;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          const int c4 = 4 * (sl + 16 * i);
+          f32x4 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = rs * (gy[i][e] - s1 - xh[i][e] * s2) + dv[it][i][e];
+          *(f32x4*)(dr + c4) = o;
+          if (ln.cast_out) {
+            const uint2 pk = {pack2bf(sc * o[0], sc * o[1]), pack2bf(sc * o[2], sc * o[3])};
+            *(uint2*)(ln.cast_out + (size_t)row * LNB_D + c4) = pk;
+          }
+        }
+      }
+    }
+  }
+  // per-column partial sums of dgamma / dbeta: combine the 4 row groups of a wave, then the 4 waves through LDS
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int o = 16; o < 64; o <<= 1) {
+        ag[i][e] += __shfl_xor(ag[i][e], o, 64);
+        ab[i][e] += __shfl_xor(ab[i][e], o, 64);
+      }
+  __syncthreads();
+  float* red = (float*)smem;                   // [2][4][192]
+  if (gq == 0) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      *(f32x4*)&red[(0 * 4 + w) * LNB_D + 4 * (sl + 16 * i)] = ag[i];
+      *(f32x4*)&red[(1 * 4 + w) * LNB_D + 4 * (sl + 16 * i)] = ab[i];
+    }
+  }
+  __syncthreads();
+  if (tid < LNB_D) {
+    const float pg = red[0 * LNB_D + tid] + red[1 * LNB_D + tid] + red[2 * LNB_D + tid] + red[3 * LNB_D + tid];
+    const float pb = red[4 * LNB_D + tid] + red[5 * LNB_D + tid] + red[6 * LNB_D + tid] + red[7 * LNB_D + tid];
+    ln.part[(size_t)blockIdx.x * 2 * LNB_D + tid] = pg;
+    ln.part[(size_t)blockIdx.x * 2 * LNB_D + LNB_D + tid] = pb;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ TN (wgrad)
 constexpr int TN_LD = 288;                 // bytes per LDS row (256 B of data + 32 B pad: tr reads conflict-free)
 constexpr int TN_TILE = 64 * TN_LD;        // 18 KiB per operand tile
@@ -1437,6 +1650,30 @@ bool tn192d_plan(const DkdTnProblem& q, TnProb* out, int min_tiles, int target_b
   return true;
 }
 }  // namespace
+
+extern "C" int dkd_gemm_nt_lnbwd(const void* A, const void* W, int32_t M, int32_t K, int32_t lda, int32_t ldb, const float* x, int32_t ldx,
+                                 const float* gamma, const float* mean, const float* rstd, float* dx, int32_t lddx, float* dgamma,
+                                 float* dbeta, float* ws, void* cast_out, const float* rowscale, int32_t rows_per_sample, void* stream) {
+  DKD_CHECK_ARG(A && W && x && gamma && mean && rstd && dx && dgamma && dbeta && ws, "gemm_nt_lnbwd: null operand");
+  DKD_CHECK_ARG(M > 0 && K > 0 && K % BK == 0 && lda % 8 == 0 && ldb % 8 == 0 && ldx % 4 == 0 && lddx % 4 == 0,
+                "gemm_nt_lnbwd: K=%d must be a multiple of %d, row strides 16-byte multiples", K, BK);
+  DKD_CHECK_ARG(((uintptr_t)A & 15) == 0 && ((uintptr_t)W & 15) == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)dx & 15) == 0 &&
+                    ((uintptr_t)gamma & 15) == 0 && (!cast_out || ((uintptr_t)cast_out & 7) == 0),
+                "gemm_nt_lnbwd: operands must be 16-byte aligned");
+  DKD_CHECK_ARG(!rowscale || rows_per_sample > 0, "gemm_nt_lnbwd: rowscale needs rows_per_sample");
+  DKD_CHECK_ARG((long)M * lda < (1L << 31), "gemm_nt_lnbwd: A too large for 32-bit offsets");
+  LnBwdEpi ln;
+  ln.x = x; ln.gamma = gamma; ln.mean = mean; ln.rstd = rstd; ln.dx = dx; ln.part = ws;
+  ln.cast_out = (bf16_t*)cast_out; ln.rowscale = rowscale; ln.ldx = ldx; ln.lddx = lddx; ln.rows_per_sample = rows_per_sample;
+  const int nblk = cdiv(M, LNB_BM);
+  {
+    DkdProbeScope probe(0, 2.0 * M * LNB_D * K, 0.0, as_stream(stream));
+    hipLaunchKernelGGL(gemm_nt_lnbwd_kernel, dim3(nblk), dim3(256), 0, as_stream(stream), (const bf16_t*)A, (const bf16_t*)W, M, K, lda, ldb,
+                       ln);
+    DKD_CHECK_LAUNCH("gemm_nt_lnbwd");
+  }
+  return dkd_ln_bwd_reduce(ws, nblk, dgamma, dbeta, LNB_D, stream);
+}
 
 extern "C" int dkd_gemm_tn_group(const DkdTnProblem* probs, int32_t n, void* stream) {
   DKD_CHECK_ARG(probs && n > 0 && n <= 4, "gemm_tn_group: need 1..4 problems (n=%d)", n);

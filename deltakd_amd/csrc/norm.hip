@@ -210,6 +210,12 @@ __global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restr
 
 }  // namespace
 
+int dkd_ln_bwd_reduce(const float* part, int nblk, float* dgamma, float* dbeta, int D, void* stream) {
+  hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3(cdiv(2 * D, 64), LNR_CHUNKS), dim3(256), 0, as_stream(stream), part, nblk, dgamma, dbeta, D);
+  DKD_CHECK_LAUNCH("layernorm_bwd_reduce");
+  return DKD_OK;
+}
+
 extern "C" int dkd_layernorm_fwd(const float* x, int32_t ldx, DkdRowMap xmap, const float* gamma, const float* beta, void* y,
                                  float* mean, float* rstd, int32_t M, int32_t D, float eps, int32_t y_is_f32, void* stream) {
   DKD_CHECK_ARG(x && gamma && beta && y, "layernorm_fwd: null operand");
@@ -245,9 +251,6 @@ extern "C" int dkd_layernorm_bwd(const void* dy, int32_t dy_is_f32, const float*
   }
 #undef LNB_ARGS
   DKD_CHECK_LAUNCH("layernorm_bwd");
-  if (ws) {
-    hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3(cdiv(2 * D, 64), LNR_CHUNKS), dim3(256), 0, st, ws, (int)grid.x, dgamma, dbeta, D);
-    DKD_CHECK_LAUNCH("layernorm_bwd_reduce");
-  }
+  if (ws) return dkd_ln_bwd_reduce(ws, (int)grid.x, dgamma, dbeta, D, stream);
   return DKD_OK;
 }

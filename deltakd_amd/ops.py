@@ -171,6 +171,17 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, *, M=None, xmap=I
     return dx
 
 
+def gemm_nt_lnbwd(a, w, x, gamma, mean, rstd, dx, dgamma, dbeta, ws, *, cast_out=None, rowscale=None, rows_per_sample=0):
+    """dx += LN'(a @ w^T) with LayerNorm width 192: the dgrad GEMM whose epilogue is the LayerNorm backward (include/dkd.h).
+    a bf16 [M, K], w bf16 [192, K]; x, dx f32 [M, 192]; ws f32 scratch of layernorm_bwd's size; cast_out bf16 [M, 192] optional."""
+    assert a.dtype == BF16 and w.dtype == BF16 and w.shape[0] == 192 and x.dtype == F32 and dx.dtype == F32 and ws.dtype == F32
+    M, K = a.shape
+    check(lib().dkd_gemm_nt_lnbwd(ptr(a), ptr(w), M, K, a.stride(0), w.stride(0), ptr(x), x.stride(0), ptr(gamma), ptr(mean), ptr(rstd),
+                                  ptr(dx), dx.stride(0), ptr(dgamma), ptr(dbeta), ptr(ws), ptr(cast_out), ptr(rowscale), rows_per_sample,
+                                  stream()), "gemm_nt_lnbwd")
+    return dx
+
+
 def im2col_patches(img, p):
     assert img.dtype == F32 and img.is_contiguous() and img.dim() == 4
     B, Cc, H, W = img.shape

@@ -133,6 +133,15 @@ int dkd_layernorm_bwd(const void* dy, int32_t dy_is_f32, const float* x, int32_t
                       const float* mean, const float* rstd, float* dx, int32_t lddx, DkdRowMap dxmap, int32_t accumulate,
                       float* dgamma, float* dbeta, int32_t M, int32_t D, float* ws, void* stream);
 
+/* Fused dgrad GEMM + LayerNorm backward for LayerNorm width D = 192 (the DeiT-tiny student; [3P] timm Block: the dgrad of fc1 /
+ * qkv feeds the backward of norm2 / norm1): dT = A[M,K] W[192,K]^T stays on chip (f32) and
+ *     dx[m,:] += LN'(dT[m,:]) ; dgamma += sum_m dT xhat ; dbeta += sum_m dT        (same arithmetic as dkd_layernorm_bwd, accumulate = 1)
+ * cast_out (optional, bf16 [M,192]) = rowscale[m / rows_per_sample] * (updated dx): the scale-cast that opens the next branch.
+ * ws: dkd_layernorm_bwd_workspace_bytes(M, 192) bytes.  K % 64 == 0. */
+int dkd_gemm_nt_lnbwd(const void* A, const void* W, int32_t M, int32_t K, int32_t lda, int32_t ldb, const float* x, int32_t ldx,
+                      const float* gamma, const float* mean, const float* rstd, float* dx, int32_t lddx, float* dgamma, float* dbeta,
+                      float* ws, void* cast_out, const float* rowscale, int32_t rows_per_sample, void* stream);
+
 /* ---------------------------------------------------------------- data movement / elementwise */
 /* img f32 [B, C, H, W] -> patches bf16 [B*(H/p)*(W/p), C*p*p] in Conv2d weight order (c, i, j). ([3P] PatchEmbed) */
 int dkd_im2col_patches(const float* img, void* patches, int32_t B, int32_t C, int32_t H, int32_t W, int32_t p, void* stream);

@@ -45,6 +45,42 @@ def test_gemm_nt_plain(ops, M, N, K):
     close(ops.gemm_nt(a, b, out_f32=True), ref, 2e-5 * math.sqrt(K), "f32 out")
 
 
+@pytest.mark.parametrize("M,K,fused_cast", [(300, 768, True), (50 * 197, 576, False), (130, 64, True)])
+def test_gemm_nt_lnbwd(ops, M, K, fused_cast):
+    """dkd_gemm_nt_lnbwd (dgrad GEMM with the LayerNorm backward as its epilogue, D = 192) against torch autograd through
+    F.layer_norm on the same operands: dx accumulates, dgamma / dbeta accumulate, optional row-scaled bf16 copy of the updated dx."""
+    import torch.nn.functional as F
+    D, rps = 192, 10
+    a = rnd(M, K, seed=201).to(BF16)
+    w = rnd(D, K, scale=0.05, seed=202).to(BF16)
+    x = rnd(M, D, seed=203, scale=2.0) + 0.5
+    gamma = 1.0 + 0.1 * rnd(D, seed=204)
+    dx0 = rnd(M, D, seed=205)
+    xr = x.clone().requires_grad_(True)
+    gr = gamma.clone().requires_grad_(True)
+    br = torch.zeros(D, device=dev(), requires_grad=True)
+    y = F.layer_norm(xr, (D,), gr, br, eps=1e-6)
+    dT = a.float() @ w.float().t()
+    y.backward(dT)
+    mu = x.mean(1)
+    rstd = torch.rsqrt(x.var(1, unbiased=False) + 1e-6)
+    dx = dx0.clone()
+    dgamma = torch.full((D,), 0.5, device=dev())
+    dbeta = torch.full((D,), -0.25, device=dev())
+    ws = torch.empty(2 * D * ((M + 63) // 64), device=dev())
+    nsamp = (M + rps - 1) // rps
+    scale = (torch.arange(nsamp, device=dev()) % 3).float() * 0.5
+    cast = torch.empty(M, D, device=dev(), dtype=BF16) if fused_cast else None
+    ops.gemm_nt_lnbwd(a, w, x, gamma, mu.contiguous(), rstd.contiguous(), dx, dgamma, dbeta, ws, cast_out=cast,
+                      rowscale=scale if fused_cast else None, rows_per_sample=rps if fused_cast else 0)
+    close(dx, dx0 + xr.grad, 2e-5 * math.sqrt(K) * 4, "dx")
+    close(dgamma - 0.5, gr.grad, 1e-4, "dgamma")
+    close(dbeta + 0.25, br.grad, 1e-4, "dbeta")
+    if fused_cast:
+        want = (dx0 + xr.grad) * scale[torch.arange(M, device=dev()) // rps][:, None]
+        close(cast, want, 1e-2, "row-scaled bf16 copy")
+
+
 def test_gemm_nt_epilogues(ops):
     from deltakd_amd.ffi import RowMap, strip_map
     B, Nt, D, Hd = 6, 17, 128, 256

@@ -195,7 +195,11 @@ __device__ __forceinline__ void nt_epilogue(const DkdGemm& g, const int vec_ok, 
 #pragma unroll
         for (int s = 0; s < SW; ++s) {
           const int m = m0 + half * 64 + r0 + RPP * s;
-          if (m < g.M) pre[s] = *(const uint4*)&((const bf16_t*)g.preact)[(size_t)m * g.ldp + n];
+          if (m < g.M) {                 // read once, never again: do not let it displace dH / W in the L2
+            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+            const u32x4 t = __builtin_nontemporal_load((const u32x4*)&((const bf16_t*)g.preact)[(size_t)m * g.ldp + n]);
+            pre[s] = uint4{t.x, t.y, t.z, t.w};
+          }
         }
       }
 #pragma unroll

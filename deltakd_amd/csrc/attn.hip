@@ -10,6 +10,8 @@
 // accumulator registers as its B operand (k-slot permutation key(g,j) = 4g+j | 16+4g+(j-4), matched on the V side by two
 // ds_read_b64_tr_b16 hardware-transposed reads).  Nothing but K/V ever touches LDS.
 // The qkv operand is the packed output of the qkv Linear ([B, N, 3, H, 64]) read in place: no head-split copy.
+#include <utility>
+
 #include "common.h"
 
 namespace {
@@ -489,6 +491,320 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(const bf16_t* __restri
   else attn_bwd_dkv_body<NT>(bh, qkv, out, dout, lse, dqkv, N, H);
 }
 
+// ---- LDS reads whose position in the instruction stream is fixed by the source --------------------------------------------------------
+// The compiler issues a ds_read just before its first use (it is at the register limit here), so a wave with one partner on its SIMD
+// sits in s_waitcnt for most of every step.  These wrappers are volatile asm: they stay in program order, and the data is only handed
+// to the compiler by lds_wait<N>(...), an s_waitcnt lgkmcnt(N) that is tied ("+v") to the registers it releases.  Rules for the caller:
+// every read issued must be released by a later lds_wait before its register dies, N counts the reads issued after the ones being
+// released (LDS returns in order), and no compiler-generated LDS access may sit between an issue and its release.
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+struct TrPair {
+  u32x2 lo, hi;
+  __device__ __forceinline__ bf16x8 get() const { return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3)); }
+};
+template <int OFF>
+__device__ __forceinline__ void lds_issue_row(uint32_t a, u32x4& v) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(a), "n"(OFF));
+}
+template <int OFF>
+__device__ __forceinline__ void lds_issue_tr(uint32_t a, TrPair& t) {       // rows r and r + 16 of a transposed 16-bit fragment
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(t.lo) : "v"(a), "n"(OFF));
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(t.hi) : "v"(a), "n"(OFF + 16 * KV_LD));
+}
+template <int N>
+__device__ __forceinline__ void lds_wait(u32x4& a, u32x4& b, u32x4& c, u32x4& d) {
+  asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N < 15 ? N : 15));   // the counter has 4 bits
+}
+template <int N>
+__device__ __forceinline__ void lds_wait(TrPair& a, TrPair& b, TrPair& c, TrPair& d) {
+  asm volatile("s_waitcnt lgkmcnt(%8)" : "+v"(a.lo), "+v"(a.hi), "+v"(b.lo), "+v"(b.hi), "+v"(c.lo), "+v"(c.hi), "+v"(d.lo), "+v"(d.hi) : "n"(N < 15 ? N : 15));
+}
+__device__ __forceinline__ bf16x8 as_bf(const u32x4& v) { return __builtin_bit_cast(bf16x8, v); }
+__device__ __forceinline__ f32x4 as_f4(const u32x4& v) { return __builtin_bit_cast(f32x4, v); }
+
+template <int... I, class F>
+__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, I...>, F&& f) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  static_for_impl(std::make_integer_sequence<int, N>{}, f);
+}
+
+// The whole backward of one head in one workgroup of 8 waves, persistent over heads (one workgroup per CU).  The two-kernel form above
+// spends two thirds of its wave cycles waiting: every workgroup stages its operands, then every wave fetches its own q / dO / O (or
+// k / v) fragments from global memory tile by tile, and nothing covers those round trips.  Here q, k, v, dO of the head are ALL in LDS
+// (4 x NT x 16 rows x 160 B = 140 KB at NT = 14), every MFMA operand is an LDS read, delta = rowsum(dO o O) is formed while the rows
+// pass through registers, and the NEXT head's rows are fetched into registers while this head's dK / dV phase runs, so the only global
+// latency a CU ever waits for is its first head's.  Phase A (dQ: waves own query tiles) and phase B (dK, dV: waves own key tiles) only
+// read LDS, so there is no barrier between them; the second-round tiles of the two phases go to different SIMDs (13 tiles over 8
+// waves leaves 5 second-round tiles per phase).
+//
+// Both phases walk NT / 2 steps of 32 rows with a hand-laid software pipeline over the pinned LDS reads above:
+//     release rows(t) -> request transposed(t) -> S, dP MFMAs -> request rows(t + 1) -> exp / dS on the VALU
+//                     -> release transposed(t) -> dQ | dK, dV MFMAs
+// so each LDS round trip has the MFMA + VALU work of half a step to hide behind.
+template <int NT>
+__global__ __launch_bounds__(512, 1) void attn_bwd_head_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out,
+                                                            const bf16_t* __restrict__ dout, const float* __restrict__ lse,
+                                                            bf16_t* __restrict__ dqkv, int N, int H, int n_heads) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int ROWS = NT * 16, REG = ROWS * KV_LD, STEP = 32 * KV_LD;
+  static_assert(NT / 2 * STEP + 16 * KV_LD + 128 < 65536 && NT % 2 == 0, "LDS immediates are 16 bit");
+  char* Qs = smem;
+  char* Ks = Qs + REG;
+  char* Vs = Ks + REG;
+  char* dOs = Vs + REG;
+  float* lse_s = (float*)(dOs + REG);
+  float* ndl_s = lse_s + ROWS;                 // -rowsum(dO o O) / 8
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int i16 = lane & 15, fg = lane >> 4;
+  const int D = H * 64, ld = 3 * D;
+  const float c = 0.125f * LOG2E;
+  const int nt = (N + 15) >> 4;
+
+  // Register image of the next head.  FI full passes of 512 row chunks (16 B) hold q, k, v, dO, O of the same chunk per thread; the last
+  // 32 rows (ROWS * 8 is an odd multiple of 256) are 256 chunks x 5 tensors packed into 3 registers: threads 0-255 hold q and v,
+  // threads 256-511 hold k, dO and O of chunk tid - 256, so dO and O of one row chunk always meet in one thread for delta.
+  constexpr int FI = ROWS * 8 / 512;
+  constexpr bool TAIL = (ROWS * 8) % 512 != 0;
+  constexpr int NR = FI * 5 + (TAIL ? 3 : 0);
+  bf16x8 reg[NR];
+  float rl = 0.f;
+  uint32_t oq[FI + 1], oo[FI + 1];               // element offsets of this thread's chunks inside a head's q rows / O rows
+  bool ok[FI + 1];
+#pragma unroll
+  for (int it = 0; it <= FI; ++it) {
+    const int idx = it < FI ? tid + 512 * it : 512 * FI + (tid & 255), row = idx >> 3, ch = idx & 7;
+    ok[it] = row < N;
+    oq[it] = (uint32_t)(row * ld + ch * 8);
+    oo[it] = (uint32_t)(row * D + ch * 8);
+  }
+  auto fetch = [&](int bh) {
+    const int b = bh / H, h = bh % H;
+    const bf16_t* base = qkv + (size_t)b * N * ld + h * 64;
+    const bf16_t* obase = out + (size_t)b * N * D + h * 64;
+    const bf16_t* dobase = dout + (size_t)b * N * D + h * 64;
+    const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int r = 0; r < NR; ++r) reg[r] = z;
+#pragma unroll
+    for (int it = 0; it < FI; ++it)
+      if (ok[it]) {
+        reg[5 * it + 0] = *(const bf16x8*)(base + oq[it]);
+        reg[5 * it + 1] = *(const bf16x8*)(base + D + oq[it]);
+        reg[5 * it + 2] = *(const bf16x8*)(base + 2 * D + oq[it]);
+        reg[5 * it + 3] = *(const bf16x8*)(dobase + oo[it]);
+        reg[5 * it + 4] = *(const bf16x8*)(obase + oo[it]);
+      }
+    if constexpr (TAIL) {
+      if (ok[FI]) {
+        const bool up = tid >= 256;
+        reg[5 * FI + 0] = *(const bf16x8*)(base + (up ? D : 0) + oq[FI]);
+        reg[5 * FI + 1] = up ? *(const bf16x8*)(dobase + oo[FI]) : *(const bf16x8*)(base + 2 * D + oq[FI]);
+        if (up) reg[5 * FI + 2] = *(const bf16x8*)(obase + oo[FI]);
+      }
+    }
+    rl = tid < N ? lse[((size_t)b * H + h) * N + tid] * LOG2E : 0.f;
+  };
+  auto rowdot = [&](const bf16x8& a, const bf16x8& b_) {      // partial rowsum(dO o O) of one chunk, summed over the row's 8 chunk lanes
+    float d = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) d += (float)a[e] * (float)b_[e];
+    d += __shfl_xor(d, 1, 64);
+    d += __shfl_xor(d, 2, 64);
+    d += __shfl_xor(d, 4, 64);
+    return d * -0.125f;
+  };
+  auto stage = [&]() {
+#pragma unroll
+    for (int it = 0; it < FI; ++it) {
+      const int idx = tid + 512 * it, row = idx >> 3, ch = idx & 7, off = row * KV_LD + ch * 16;
+      const float d = rowdot(reg[5 * it + 3], reg[5 * it + 4]);
+      *(bf16x8*)(Qs + off) = reg[5 * it + 0];
+      *(bf16x8*)(Ks + off) = reg[5 * it + 1];
+      *(bf16x8*)(Vs + off) = reg[5 * it + 2];
+      *(bf16x8*)(dOs + off) = reg[5 * it + 3];
+      if (ch == 0) ndl_s[row] = d;
+    }
+    if constexpr (TAIL) {
+      const int idx = 512 * FI + (tid & 255), row = idx >> 3, ch = idx & 7, off = row * KV_LD + ch * 16;
+      const bool up = tid >= 256;
+      const float d = rowdot(reg[5 * FI + 1], reg[5 * FI + 2]);
+      *(bf16x8*)((up ? Ks : Qs) + off) = reg[5 * FI + 0];
+      *(bf16x8*)((up ? dOs : Vs) + off) = reg[5 * FI + 1];
+      if (up && ch == 0) ndl_s[row] = d;
+    }
+    if (tid < ROWS) lse_s[tid] = rl;
+  };
+
+  // LDS byte addresses of this lane's fragments: one VGPR per region, everything else is an instruction immediate
+  const uint32_t lds0 = (uint32_t)(uintptr_t)LDS_PTR(smem);
+  const uint32_t rowoff = lds0 + i16 * KV_LD + fg * 16;                              // + 16 tile KV_LD + 64 ks
+  const uint32_t troff = lds0 + (4 * fg + (i16 >> 2)) * KV_LD + (i16 & 3) * 8;       // + 32 step KV_LD + 32 dt (+ 16 rows in the pair)
+  const uint32_t q_row = rowoff, k_row = rowoff + REG, v_row = rowoff + 2 * REG, do_row = rowoff + 3 * REG;
+  const uint32_t q_tr = troff, k_tr = troff + REG, do_tr = troff + 3 * REG;
+  const uint32_t st_a = lds0 + 4 * REG + 16 * fg;                                    // lse_s[4 fg ..]; ndl_s is ROWS * 4 bytes further
+
+  int bh = blockIdx.x;
+  if (bh >= n_heads) return;
+  fetch(bh);
+  for (; bh < n_heads; bh += gridDim.x) {
+    const int b = bh / H, h = bh % H;
+    stage();
+    __syncthreads();
+
+    // ---- phase A: dQ.  s[r] = S^T[key 4 fg + r][query i16].  Padded keys need no mask: their K rows are zero in LDS, so whatever
+    // (finite) dS they get multiplies zeros in dQ.
+    for (int qt = w; qt < nt; qt += 8) {
+      const int qrow = qt * 16 + i16;
+      bf16x8 qf[2], dof[2];
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        qf[ks] = *(const bf16x8*)(Qs + qrow * KV_LD + fg * 16 + ks * 64);
+        dof[ks] = *(const bf16x8*)(dOs + qrow * KV_LD + fg * 16 + ks * 64);
+      }
+      const float nd8 = ndl_s[qrow] * 8.f;          // -delta
+      const float lq3 = lse_s[qrow] + 3.f;          // p/8 = exp2(s c - lse log2e - 3): the 1/sqrt(64) of dS rides in the exponent
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // nothing of the compiler's is in flight when the pinned reads start
+      f32x4 dq[4];
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      u32x4 ka[2][2], va[2][2];                      // [16-key tile of the step][k half]
+      lds_issue_row<0>(k_row, ka[0][0]), lds_issue_row<64>(k_row, ka[0][1]);
+      lds_issue_row<16 * KV_LD>(k_row, ka[1][0]), lds_issue_row<16 * KV_LD + 64>(k_row, ka[1][1]);
+      lds_issue_row<0>(v_row, va[0][0]), lds_issue_row<64>(v_row, va[0][1]);
+      lds_issue_row<16 * KV_LD>(v_row, va[1][0]), lds_issue_row<16 * KV_LD + 64>(v_row, va[1][1]);
+      static_for<NT / 2>([&](auto step) {
+        constexpr int t = decltype(step)::value, O = t * STEP;
+        lds_wait<4>(ka[0][0], ka[0][1], ka[1][0], ka[1][1]);
+        lds_wait<0>(va[0][0], va[0][1], va[1][0], va[1][1]);
+        TrPair kt_[4];
+        lds_issue_tr<O>(k_tr, kt_[0]), lds_issue_tr<O + 32>(k_tr, kt_[1]), lds_issue_tr<O + 64>(k_tr, kt_[2]), lds_issue_tr<O + 96>(k_tr, kt_[3]);
+        f32x4 s[2], dp[2];
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+          s[hf] = f32x4{0.f, 0.f, 0.f, 0.f}, dp[hf] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks) {
+            s[hf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf(ka[hf][ks]), qf[ks], s[hf], 0, 0, 0);
+            dp[hf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf(va[hf][ks]), dof[ks], dp[hf], 0, 0, 0);
+          }
+        }
+        if constexpr (t + 1 < NT / 2) {
+          constexpr int P = O + STEP;
+          lds_issue_row<P>(k_row, ka[0][0]), lds_issue_row<P + 64>(k_row, ka[0][1]);
+          lds_issue_row<P + 16 * KV_LD>(k_row, ka[1][0]), lds_issue_row<P + 16 * KV_LD + 64>(k_row, ka[1][1]);
+          lds_issue_row<P>(v_row, va[0][0]), lds_issue_row<P + 64>(v_row, va[0][1]);
+          lds_issue_row<P + 16 * KV_LD>(v_row, va[1][0]), lds_issue_row<P + 16 * KV_LD + 64>(v_row, va[1][1]);
+        }
+        f32x4 ds[2];
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) ds[hf][r] = __builtin_amdgcn_exp2f(fmaf(s[hf][r], c, -lq3)) * (dp[hf][r] + nd8);
+        const bf16x8 dsf = pack8(ds[0], ds[1]);
+        lds_wait<(t + 1 < NT / 2) ? 8 : 0>(kt_[0], kt_[1], kt_[2], kt_[3]);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) dq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kt_[dt].get(), dsf, dq[dt], 0, 0, 0);
+      });
+      if (qrow < N) {
+        bf16_t* dp_ = dqkv + ((size_t)b * N + qrow) * ld + h * 64 + 4 * fg;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) store4bf(dp_ + dt * 16, dq[dt], 1.f);
+      }
+    }
+
+    const int nxt = bh + gridDim.x;
+    if (nxt < n_heads) fetch(nxt);                  // lands during phase B
+
+    // ---- phase B: dK, dV.  s[r] = S[query 4 fg + r][key i16]
+    for (int rnd = 0; rnd * 8 < nt; ++rnd) {
+      const int kt = rnd * 8 + ((w - 5 * rnd) & 7);
+      if (kt >= nt) continue;
+      const int krow = kt * 16 + i16;
+      bf16x8 kf[2], vf[2];
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        kf[ks] = *(const bf16x8*)(Ks + krow * KV_LD + fg * 16 + ks * 64);
+        vf[ks] = *(const bf16x8*)(Vs + krow * KV_LD + fg * 16 + ks * 64);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      f32x4 dk[4], dv[4];
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        dk[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        dv[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+      u32x4 qa[2][2], da[2][2], lq[2], nl[2];        // [16-query tile of the step][k half]; row statistics of the two tiles
+      lds_issue_row<0>(q_row, qa[0][0]), lds_issue_row<64>(q_row, qa[0][1]);
+      lds_issue_row<16 * KV_LD>(q_row, qa[1][0]), lds_issue_row<16 * KV_LD + 64>(q_row, qa[1][1]);
+      lds_issue_row<0>(do_row, da[0][0]), lds_issue_row<64>(do_row, da[0][1]);
+      lds_issue_row<16 * KV_LD>(do_row, da[1][0]), lds_issue_row<16 * KV_LD + 64>(do_row, da[1][1]);
+      lds_issue_row<0>(st_a, lq[0]), lds_issue_row<64>(st_a, lq[1]);
+      lds_issue_row<ROWS * 4>(st_a, nl[0]), lds_issue_row<ROWS * 4 + 64>(st_a, nl[1]);
+      static_for<NT / 2>([&](auto step) {
+        constexpr int t = decltype(step)::value, O = t * STEP;
+        lds_wait<8>(qa[0][0], qa[0][1], qa[1][0], qa[1][1]);
+        lds_wait<4>(da[0][0], da[0][1], da[1][0], da[1][1]);
+        TrPair td[4], tq[4];
+        lds_issue_tr<O>(do_tr, td[0]), lds_issue_tr<O + 32>(do_tr, td[1]), lds_issue_tr<O + 64>(do_tr, td[2]), lds_issue_tr<O + 96>(do_tr, td[3]);
+        lds_issue_tr<O>(q_tr, tq[0]), lds_issue_tr<O + 32>(q_tr, tq[1]), lds_issue_tr<O + 64>(q_tr, tq[2]), lds_issue_tr<O + 96>(q_tr, tq[3]);
+        f32x4 s[2], dp[2];
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+          s[hf] = f32x4{0.f, 0.f, 0.f, 0.f}, dp[hf] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks) {
+            s[hf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf(qa[hf][ks]), kf[ks], s[hf], 0, 0, 0);
+            dp[hf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf(da[hf][ks]), vf[ks], dp[hf], 0, 0, 0);
+          }
+        }
+        lds_wait<16>(lq[0], lq[1], nl[0], nl[1]);    // the statistics were requested before the 16 transposed reads of this step
+        f32x4 pp[2], dss[2];
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+          const f32x4 l = as_f4(lq[hf]), n = as_f4(nl[hf]);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float p = __builtin_amdgcn_exp2f(fmaf(s[hf][r], c, -l[r]));
+            pp[hf][r] = p;
+            dss[hf][r] = p * fmaf(dp[hf][r], 0.125f, n[r]);
+          }
+        }
+        const bf16x8 pf = pack8(pp[0], pp[1]);
+        const bf16x8 dsf = pack8(dss[0], dss[1]);
+        if constexpr (t + 1 < NT / 2) {
+          constexpr int P = O + STEP, S4 = (t + 1) * 128;
+          lds_issue_row<P>(q_row, qa[0][0]), lds_issue_row<P + 64>(q_row, qa[0][1]);
+          lds_issue_row<P + 16 * KV_LD>(q_row, qa[1][0]), lds_issue_row<P + 16 * KV_LD + 64>(q_row, qa[1][1]);
+          lds_issue_row<P>(do_row, da[0][0]), lds_issue_row<P + 64>(do_row, da[0][1]);
+          lds_issue_row<P + 16 * KV_LD>(do_row, da[1][0]), lds_issue_row<P + 16 * KV_LD + 64>(do_row, da[1][1]);
+          lds_issue_row<S4>(st_a, lq[0]), lds_issue_row<S4 + 64>(st_a, lq[1]);
+          lds_issue_row<ROWS * 4 + S4>(st_a, nl[0]), lds_issue_row<ROWS * 4 + S4 + 64>(st_a, nl[1]);
+        }
+        constexpr int LATER = (t + 1 < NT / 2) ? 12 : 0;
+        lds_wait<LATER + 8>(td[0], td[1], td[2], td[3]);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(td[dt].get(), pf, dv[dt], 0, 0, 0);
+        lds_wait<LATER>(tq[0], tq[1], tq[2], tq[3]);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tq[dt].get(), dsf, dk[dt], 0, 0, 0);
+      });
+      if (krow < N) {
+        bf16_t* kp_ = dqkv + ((size_t)b * N + krow) * ld + D + h * 64 + 4 * fg;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          store4bf(kp_ + dt * 16, dk[dt], 1.f);
+          store4bf(kp_ + D + dt * 16, dv[dt], 1.f);
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
 template <typename K>
 int set_smem(K kernel, int bytes) {
   if (bytes <= 65536) return 0;
@@ -560,6 +876,29 @@ extern "C" int dkd_attn_bwd(const void* qkv, const void* out, const void* dout, 
   const int smem1 = 2 * nt * 16 * KV_LD;
   const int smem2 = smem1 + 2 * nt * 16 * 4;
   const int nbh = B * H;
+  static int n_cu = 0;
+  if (!n_cu) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) {
+      dkd_set_error("attn_bwd: cannot query the device");
+      return DKD_ERR_HIP;
+    }
+    n_cu = prop.multiProcessorCount;
+  }
+  static const bool no_head = getenv("DKD_ATTN_BWD_SPLIT") != nullptr;
+  if ((nt == 8 || nt == 14) && nbh >= n_cu && !no_head) {     // one persistent workgroup per CU, the whole head in LDS
+    const int smem = 4 * nt * 16 * KV_LD + 2 * nt * 16 * 4;
+    DISPATCH_NT(nt, {
+      if constexpr (T == 8 || T == 14) {
+        if (int rc = set_smem(attn_bwd_head_kernel<T>, smem)) return rc;
+        hipLaunchKernelGGL(attn_bwd_head_kernel<T>, dim3(n_cu), dim3(512), smem, as_stream(stream), (const bf16_t*)qkv, (const bf16_t*)out,
+                           (const bf16_t*)dout, lse, (bf16_t*)dqkv, N, H, nbh);
+      }
+    });
+    DKD_CHECK_LAUNCH("attn_bwd_head");
+    return DKD_OK;
+  }
   const int grid = ((nbh + 7) / 8) * 16;           // groups of 16 blocks: 8 heads x {dQ half, dK/dV half}
   DISPATCH_NT(nt, {
     if (int rc = set_smem(attn_bwd_kernel<T>, smem2)) return rc;

@@ -254,6 +254,27 @@ def test_attn_fwd_persistent_kernel(ops, B, N, H):
     close(lse.view(B, H, N), ref_lse, 1e-3, "lse (ring)")
 
 
+@pytest.mark.parametrize("B,N,H", [(100, 197, 3), (30, 198, 12), (40, 100, 8), (90, 128, 3), (24, 224, 12), (22, 193, 12), (86, 65, 3)])
+def test_attn_bwd_per_head_kernel(ops, B, N, H):
+    """>= one head per CU routes the backward to the persistent one-workgroup-per-head kernel (q, k, v, dO of the head in LDS, next
+    head prefetched into registers): uneven heads per workgroup, the 8- and 14-tile instantiations, N on a 16- / 32-row boundary, one
+    row into the packed tail pass (193), a full tail (224)."""
+    qkv = rnd(B * N, 3 * H * 64, scale=1.5, seed=23).to(BF16)
+    out, lse = ops.attn_fwd(qkv, B, N, H)
+    dout = rnd(B * N, H * 64, seed=24).to(BF16)
+    x = qkv.float().requires_grad_(True)
+    r, _ = ref_attention(x, B, N, H)
+    r.backward(dout.float())
+    dqkv = ops.attn_bwd(qkv, out, dout, lse, B, N, H)
+    g = x.grad.view(B, N, 3, H, 64)
+    d = dqkv.float().view(B, N, 3, H, 64)
+    for i, nm in enumerate("qkv"):
+        close(d[:, :, i], g[:, :, i], 3e-2, f"d{nm} (per head)")
+    for b in (0, B // 2, B - 1):                    # every workgroup pass, first and last head, not only on average
+        for i, nm in enumerate("qkv"):
+            close(d[b, :, i], g[b, :, i], 3e-2, f"d{nm} image {b}")
+
+
 @pytest.mark.parametrize("M,D", [(7, 64), (300, 192), (129, 768), (50, 1024)])
 def test_layernorm(ops, M, D):
     x = rnd(M, D, scale=2.0, seed=30) + 0.5

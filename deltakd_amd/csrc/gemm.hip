@@ -161,9 +161,33 @@ __device__ __forceinline__ void nt_store16(bf16_t* p, const uint4 v) {
 // FAST 3: C(f32) = resid + acc + bias with identity row maps, no row scale (the teacher's proj / fc2; bf16 tap optional) -- compiled
 // without the generic path's per-vector flag tests and row-map arithmetic.  7: C(f32) = resid + rowscale[sample] * (acc + bias), the
 // student's proj / fc2 under DropPath.  0: generic.
+// residual rows of one thread of the FAST 3 / 7 epilogue (2 halves x SW sweeps x 8 columns), requested before the K loop
+template <int BN>
+struct ResidRegs {
+  static constexpr int SW = 64 / (256 / (BN / 8));
+  f32x4 lo[2][SW], hi[2][SW];
+};
+template <int BN>
+__device__ __forceinline__ void resid_prefetch(const DkdGemm& g, ResidRegs<BN>& r, const int m0, const int n0, const int tid) {
+  constexpr int TPR = BN / 8, RPP = 256 / TPR, SW = 64 / RPP;
+  const int n = n0 + (tid % TPR) * 8, r0 = tid / TPR;
+#pragma unroll
+  for (int half = 0; half < 2; ++half)
+#pragma unroll
+    for (int s = 0; s < SW; ++s) {
+      const int m = m0 + half * 64 + r0 + RPP * s;
+      r.lo[half][s] = f32x4{0.f, 0.f, 0.f, 0.f}, r.hi[half][s] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (m < g.M && n < g.N) {
+        const float* rp = &g.resid[(size_t)m * g.ldr + n];
+        r.lo[half][s] = *(const f32x4*)rp;
+        r.hi[half][s] = *(const f32x4*)(rp + 4);
+      }
+    }
+}
+
 template <int BN, int NJ, int FAST>
 __device__ __forceinline__ void nt_epilogue(const DkdGemm& g, const int vec_ok, char* smem, f32x4 (&acc)[4][NJ], const int m0,
-                                            const int n0, const int tid, const int wr, const int wc) {
+                                            const int n0, const int tid, const int wr, const int wc, const ResidRegs<BN>* pre = nullptr) {
   const int lane = tid & 63, frow = lane & 15, fg = lane >> 4;
   float* cs = (float*)smem;
   __syncthreads();
@@ -236,12 +260,8 @@ __device__ __forceinline__ void nt_epilogue(const DkdGemm& g, const int vec_ok, 
       f32x4 r0v[SW], r1v[SW];
 #pragma unroll
       for (int s = 0; s < SW; ++s) {
-        const int m = m0 + half * 64 + r0 + RPP * s;
-        if (m < g.M) {
-          const float* rp = &g.resid[(size_t)m * g.ldr + n];
-          r0v[s] = *(const f32x4*)rp;
-          r1v[s] = *(const f32x4*)(rp + 4);
-        }
+        r0v[s] = pre->lo[half][s];
+        r1v[s] = pre->hi[half][s];
       }
 #pragma unroll
       for (int s = 0; s < SW; ++s) {
@@ -370,6 +390,11 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const DkdGemm g, const 
 
   const int frow = lane & 15, fg = lane >> 4, fswz = (frow >> 1) & 7;
 
+  // f32 residual epilogues: the rows this thread will add to are requested NOW and arrive under the K loop; read in the epilogue
+  // (after the tile has been staged) their round trip was exposed once per tile -- K = 768 is only 12 steps
+  ResidRegs<BN> rres;
+  if (FAST == 3 || FAST == 7) resid_prefetch<BN>(g, rres, m0, n0, tid);
+
   stage(0, 0);
   for (int kt = 0; kt < KT; ++kt) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -392,7 +417,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const DkdGemm g, const 
     }
   }
 
-  nt_epilogue<BN, NJ, FAST>(g, vec_ok, smem, acc, m0, n0, tid, wr, wc);
+  nt_epilogue<BN, NJ, FAST>(g, vec_ok, smem, acc, m0, n0, tid, wr, wc, &rres);
 }
 
 // ---- 256 x 256 tile, 8 waves (2 x 4, 128 x 64 per wave), PERSISTENT, one workgroup per CU: for the wide teacher GEMMs.
@@ -608,10 +633,49 @@ __global__ __launch_bounds__(128 * WN, WN == 4 ? 1 : 2) void gemm_nt256_kernel(c
           bias8[jp] = f32x8{b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
         }
       }
+      constexpr bool FAST3 = FAST == 3;
+      if (FAST3) {
+        // C(f32) = resid + acc + bias, identity row maps, optional bf16 tap: 32 contiguous bytes per lane, 128 per row and block.
+        // C may alias resid (it does: the residual stream is updated in place), so the compiler keeps every load behind the stores
+        // before it -- row group by row group that was 8 exposed memory round trips per tile, all eight waves idle in each.  The
+        // loads are issued two row groups at a time, ahead of their stores (more spills: the accumulators hold 128 registers): 4 round trips.
+        constexpr int GB = 2;
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
+        for (int i0 = 0; i0 < 8; i0 += GB) {
+          f32x4 rr[GB][4];
+#pragma unroll
+          for (int gi = 0; gi < GB; ++gi) {
+            const int m = m0 + wr * 128 + (i0 + gi) * 16 + frow;
+            if (m < g.M) {
+              const float* rp = &g.resid[(size_t)m * g.ldr + nb];
+              rr[gi][0] = *(const f32x4*)rp, rr[gi][1] = *(const f32x4*)(rp + 4), rr[gi][2] = *(const f32x4*)(rp + 32), rr[gi][3] = *(const f32x4*)(rp + 36);
+            }
+          }
+#pragma unroll
+          for (int gi = 0; gi < GB; ++gi) {
+            const int i = i0 + gi, m = m0 + wr * 128 + i * 16 + frow;
+            if (m < g.M) {
+              const f32x8 v0 = f32x8{acc[i][0][0], acc[i][0][1], acc[i][0][2], acc[i][0][3], acc[i][1][0], acc[i][1][1], acc[i][1][2],
+                                     acc[i][1][3]} + bias8[0];
+              const f32x8 v1 = f32x8{acc[i][2][0], acc[i][2][1], acc[i][2][2], acc[i][2][3], acc[i][3][0], acc[i][3][1], acc[i][3][2],
+                                     acc[i][3][3]} + bias8[1];
+              if (g.tap) {
+                bf16_t* tp = &((bf16_t*)g.tap)[(size_t)m * g.ldt + nb];
+                *(uint4*)tp = pack8(v0);
+                *(uint4*)(tp + 32) = pack8(v1);
+              }
+              float* cp = (float*)g.C + (size_t)m * g.ldc + nb;
+              *(f32x4*)cp = rr[gi][0] + f32x4{v0[0], v0[1], v0[2], v0[3]};
+              *(f32x4*)(cp + 4) = rr[gi][1] + f32x4{v0[4], v0[5], v0[6], v0[7]};
+              *(f32x4*)(cp + 32) = rr[gi][2] + f32x4{v1[0], v1[1], v1[2], v1[3]};
+              *(f32x4*)(cp + 36) = rr[gi][3] + f32x4{v1[4], v1[5], v1[6], v1[7]};
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < (FAST3 ? 0 : 8); ++i) {
         const int m = m0 + wr * 128 + i * 16 + frow;
-        constexpr bool FAST3 = FAST == 3;
         if (FAST == 1 || FAST == 2) {
           // bf16 output, streaming stores of FULL 128-byte lines: a row's 64 columns of this wave sit in 4 lanes x 2 column
           // blocks; lanes of an even/odd row pair swap one block (DPP), so that one store instruction writes both halves of the
@@ -637,26 +701,6 @@ __global__ __launch_bounds__(128 * WN, WN == 4 ? 1 : 2) void gemm_nt256_kernel(c
           bf16_t* cp = (bf16_t*)g.C + (size_t)me * g.ldc + nb + (odd ? 32 : 0);
           if (me < g.M) __builtin_nontemporal_store(u32x4{d0.x, d0.y, d0.z, d0.w}, (u32x4*)cp);
           if (me + 1 < g.M) __builtin_nontemporal_store(u32x4{d1.x, d1.y, d1.z, d1.w}, (u32x4*)(cp + g.ldc));
-        } else if (FAST3) {
-          // C(f32) = resid + acc + bias, identity row maps, optional bf16 tap: 32 contiguous bytes per lane, 128 per row and block
-          if (m < g.M) {
-            const float* rp = &g.resid[(size_t)m * g.ldr + nb];
-            const f32x4 r00 = *(const f32x4*)rp, r01 = *(const f32x4*)(rp + 4), r10 = *(const f32x4*)(rp + 32), r11 = *(const f32x4*)(rp + 36);
-            const f32x8 v0 = f32x8{acc[i][0][0], acc[i][0][1], acc[i][0][2], acc[i][0][3], acc[i][1][0], acc[i][1][1], acc[i][1][2],
-                                   acc[i][1][3]} + bias8[0];
-            const f32x8 v1 = f32x8{acc[i][2][0], acc[i][2][1], acc[i][2][2], acc[i][2][3], acc[i][3][0], acc[i][3][1], acc[i][3][2],
-                                   acc[i][3][3]} + bias8[1];
-            if (g.tap) {
-              bf16_t* tp = &((bf16_t*)g.tap)[(size_t)m * g.ldt + nb];
-              *(uint4*)tp = pack8(v0);
-              *(uint4*)(tp + 32) = pack8(v1);
-            }
-            float* cp = (float*)g.C + (size_t)m * g.ldc + nb;
-            *(f32x4*)cp = r00 + f32x4{v0[0], v0[1], v0[2], v0[3]};
-            *(f32x4*)(cp + 4) = r01 + f32x4{v0[4], v0[5], v0[6], v0[7]};
-            *(f32x4*)(cp + 32) = r10 + f32x4{v1[0], v1[1], v1[2], v1[3]};
-            *(f32x4*)(cp + 36) = r11 + f32x4{v1[4], v1[5], v1[6], v1[7]};
-          }
         } else if (m < g.M) {
           EpiIn in[2];
 #pragma unroll

@@ -8,7 +8,7 @@ dev = "cuda:0"
 BF16 = torch.bfloat16
 shapes = [  # (name, M, N, K, epilogue)
     ("t_qkv", 50688, 2304, 768, "bias"), ("t_proj", 50688, 768, 768, "resid"), ("t_fc1", 50688, 3072, 768, "gelu"),
-    ("t_fc2", 50688, 768, 3072, "resid"), ("s_qkv", 50432, 576, 192, "bias"), ("s_fc1", 50432, 768, 192, "gelu"), ("s_fc1p", 50432, 768, 192, "gelu_pre"), ("s_fc2d", 50432, 768, 192, "dgelu"),
+    ("t_fc2", 50688, 768, 3072, "resid"), ("t_projb", 50688, 768, 768, "bias"), ("t_fc2b", 50688, 768, 3072, "bias"), ("t_fc1b", 50688, 3072, 768, "bias"), ("s_qkv", 50432, 576, 192, "bias"), ("s_fc1", 50432, 768, 192, "gelu"), ("s_fc1p", 50432, 768, 192, "gelu_pre"), ("s_fc2d", 50432, 768, 192, "dgelu"),
     ("s_fc2", 50432, 192, 768, "resid"), ("s_proj", 50432, 192, 192, "resid"),
 ]
 only = sys.argv[1:] 

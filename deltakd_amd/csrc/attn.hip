@@ -145,6 +145,47 @@ __global__ __launch_bounds__(64 * FWD_WAVES, 2) void attn_fwd_kernel(const bf16_
   }
 }
 
+// ---- LDS reads whose position in the instruction stream is fixed by the source --------------------------------------------------------
+// The compiler issues a ds_read just before its first use (it is at the register limit here), so a wave with one partner on its SIMD
+// sits in s_waitcnt for most of every step.  These wrappers are volatile asm: they stay in program order, and the data is only handed
+// to the compiler by lds_wait<N>(...), an s_waitcnt lgkmcnt(N) that is tied ("+v") to the registers it releases.  Rules for the caller:
+// every read issued must be released by a later lds_wait before its register dies, N counts the reads issued after the ones being
+// released (LDS returns in order), and no compiler-generated LDS access may sit between an issue and its release.
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+struct TrPair {
+  u32x2 lo, hi;
+  __device__ __forceinline__ bf16x8 get() const { return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3)); }
+};
+template <int OFF>
+__device__ __forceinline__ void lds_issue_row(uint32_t a, u32x4& v) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(a), "n"(OFF));
+}
+template <int OFF, int PAIR = 16 * KV_LD>
+__device__ __forceinline__ void lds_issue_tr(uint32_t a, TrPair& t) {       // rows r and r + 16 of a transposed 16-bit fragment
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(t.lo) : "v"(a), "n"(OFF));
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(t.hi) : "v"(a), "n"(OFF + PAIR));
+}
+template <int N>
+__device__ __forceinline__ void lds_wait(u32x4& a, u32x4& b, u32x4& c, u32x4& d) {
+  asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N < 15 ? N : 15));   // the counter has 4 bits
+}
+template <int N>
+__device__ __forceinline__ void lds_wait(TrPair& a, TrPair& b, TrPair& c, TrPair& d) {
+  asm volatile("s_waitcnt lgkmcnt(%8)" : "+v"(a.lo), "+v"(a.hi), "+v"(b.lo), "+v"(b.hi), "+v"(c.lo), "+v"(c.hi), "+v"(d.lo), "+v"(d.hi) : "n"(N < 15 ? N : 15));
+}
+__device__ __forceinline__ bf16x8 as_bf(const u32x4& v) { return __builtin_bit_cast(bf16x8, v); }
+__device__ __forceinline__ f32x4 as_f4(const u32x4& v) { return __builtin_bit_cast(f32x4, v); }
+
+template <int... I, class F>
+__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, I...>, F&& f) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  static_for_impl(std::make_integer_sequence<int, N>{}, f);
+}
+
 // ---- forward, persistent: one 8-wave workgroup per CU walks heads; K/V of head k+1 stream into the second LDS buffer by LDS-DMA
 // while head k is computed.  The kernel above spends 33 us staging (HBM-bound: 155 MB of K/V) and 64 us computing per teacher
 // layer and the two do not overlap -- both workgroups of a CU stage at the same time, then both compute (127 us; the layer's HBM
@@ -155,7 +196,10 @@ __global__ __launch_bounds__(64 * FWD_WAVES, 2) void attn_fwd_kernel(const bf16_
 //  * ordering: the Q fragments of head k+1 are loaded (ordinary global loads) right AFTER the DMA of head k+1 is issued; the
 //    vector-memory counter is in order, so the wait the compiler places before their first use -- forced to sit before the
 //    barrier that opens head k+1 -- also covers the DMA, without draining the output stores issued after them.
-template <int NKT>
+// NF: number of leading key tiles known to be full (N >= 16 NF); tile NF gets its padding mask through the MFMA accumulator's initial
+// value (-inf where key >= N, else 0), later tiles are all padding and skipped.  NF = -1: any N, masks applied with selects -- which
+// the compiler spreads over all NKT tiles (2 v_cndmask per score plus spilled condition masks: as much VALU work again as the softmax).
+template <int NKT, int NF>
 __global__ __launch_bounds__(512, 1) void attn_fwd_ring_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
                                                                 float* __restrict__ lse, int N, int H, int n_heads) {
   constexpr int NW = 8, ROWS = NKT * 16, MAT = ROWS * 128, BUF = 2 * MAT, NPIECE = 2 * (ROWS / 8);
@@ -211,6 +255,12 @@ __global__ __launch_bounds__(512, 1) void attn_fwd_ring_kernel(const bf16_t* __r
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) v_off[dt] = row * 128 + ((dt ^ ((row >> 1) & 3)) * 32) + 8 * (i16 & 3);
   }
+  const bf16x8 ones = __builtin_bit_cast(bf16x8, u32x4{0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u});
+  f32x4 pinit = {0.f, 0.f, 0.f, 0.f};              // accumulator start of the partial key tile
+  if (NF >= 0) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) pinit[r] = (NF * 16 + 4 * fg + r >= N) ? -INFINITY : 0.f;
+  }
   bf16x8 qcur[MAXQ][2], qnext[MAXQ][2];
   issue_dma(0);
   load_q(qcur, 0);
@@ -225,8 +275,9 @@ __global__ __launch_bounds__(512, 1) void attn_fwd_ring_kernel(const bf16_t* __r
       issue_dma(k + 1);
       load_q(qnext, k + 1);
     }
-    const char* Ks = smem + (k & 1) * BUF;
-    const char* Vs = Ks + MAT;
+    const uint32_t buf0 = (uint32_t)(uintptr_t)LDS_PTR(smem) + (k & 1) * BUF;
+    const uint32_t kb[2] = {buf0 + k_off[0], buf0 + k_off[1]};
+    const uint32_t vb[4] = {buf0 + MAT + v_off[0], buf0 + MAT + v_off[1], buf0 + MAT + v_off[2], buf0 + MAT + v_off[3]};
     const int hd = blockIdx.x + k * gridDim.x;
     const int b = hd / H, h = hd % H;
 #pragma unroll
@@ -234,20 +285,46 @@ __global__ __launch_bounds__(512, 1) void attn_fwd_ring_kernel(const bf16_t* __r
       const int qt = w + it * NW;
       if (qt < nqt) {
         const int q = qt * 16 + i16;
+        // S^T = K q: the K row fragments come through a ring of three register sets, two 16-key tiles per set, requested three sets
+        // ahead of the MFMAs that consume them (pinned reads: see lds_issue_row)
         f32x4 s[NKT];
+        constexpr int NG = NKT / 2;
+        u32x4 kr[3][4];
+        auto issue_k = [&](auto gi) {
+          constexpr int g = decltype(gi)::value;
+          lds_issue_row<(2 * g) * 2048>(kb[0], kr[g % 3][0]), lds_issue_row<(2 * g) * 2048>(kb[1], kr[g % 3][1]);
+          lds_issue_row<(2 * g + 1) * 2048>(kb[0], kr[g % 3][2]), lds_issue_row<(2 * g + 1) * 2048>(kb[1], kr[g % 3][3]);
+        };
+        static_for<(NG < 3 ? NG : 3)>(issue_k);
+        static_for<NG>([&](auto gi) {
+          constexpr int g = decltype(gi)::value, after = NG - 1 - g < 2 ? NG - 1 - g : 2;
+          lds_wait<4 * after>(kr[g % 3][0], kr[g % 3][1], kr[g % 3][2], kr[g % 3][3]);
 #pragma unroll
-        for (int kt = 0; kt < NKT; ++kt) {
-          s[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-          for (int ks = 0; ks < 2; ++ks) {
-            const bf16x8 kf = *(const bf16x8*)(Ks + k_off[ks] + kt * 2048);
-            s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qcur[it][ks], s[kt], 0, 0, 0);
+          for (int hf = 0; hf < 2; ++hf) {
+            constexpr f32x4 zero = {0.f, 0.f, 0.f, 0.f}, ninf = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+            const int t = 2 * g + hf;
+            if (NF >= 0 && t > NF) {
+              s[t] = ninf;
+            } else {
+              f32x4 a = (NF >= 0 && t == NF) ? pinit : zero;
+              a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf(kr[g % 3][2 * hf]), qcur[it][0], a, 0, 0, 0);
+              s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf(kr[g % 3][2 * hf + 1]), qcur[it][1], a, 0, 0, 0);
+            }
           }
-        }
+          if constexpr (g + 3 < NG) issue_k(std::integral_constant<int, g + 3>{});
+        });
+        // the first V fragments are requested before the softmax arithmetic: they do not depend on it
+        TrPair vr[3][4];
+        auto issue_v = [&](auto ki) {
+          constexpr int kp = decltype(ki)::value;
+          lds_issue_tr<kp * 4096, 2048>(vb[0], vr[kp % 3][0]), lds_issue_tr<kp * 4096, 2048>(vb[1], vr[kp % 3][1]);
+          lds_issue_tr<kp * 4096, 2048>(vb[2], vr[kp % 3][2]), lds_issue_tr<kp * 4096, 2048>(vb[3], vr[kp % 3][3]);
+        };
+        static_for<(NG < 2 ? NG : 2)>(issue_v);
         float mx = -INFINITY;
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt) {
-          if (kt * 16 + 16 > N) {
+          if (NF < 0 && kt * 16 + 16 > N) {
 #pragma unroll
             for (int r = 0; r < 4; ++r)
               if (kt * 16 + 4 * fg + r >= N) s[kt][r] = -INFINITY;
@@ -258,32 +335,26 @@ __global__ __launch_bounds__(512, 1) void attn_fwd_ring_kernel(const bf16_t* __r
         mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         const float mxc = mx * c;
-        float sum = 0.f;
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float pr = __builtin_amdgcn_exp2f(fmaf(s[kt][r], c, -mxc));
-            s[kt][r] = pr;
-            sum += pr;
-          }
-        sum += __shfl_xor(sum, 16, 64);
-        sum += __shfl_xor(sum, 32, 64);
+          for (int r = 0; r < 4; ++r) s[kt][r] = __builtin_amdgcn_exp2f(fmaf(s[kt][r], c, -mxc));
+        // the row sum is a fifth output tile of the P V product, against a fragment of ones: the loop is VALU-bound (exp, max, the
+        // bf16 packing), the matrix pipe is not, and the sum then is the sum of exactly the bf16 probabilities that multiply V
+        f32x4 osum = {0.f, 0.f, 0.f, 0.f};
         f32x4 o[4];
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int kp = 0; kp < NKT / 2; ++kp) {
+        static_for<NG>([&](auto ki) {
+          constexpr int kp = decltype(ki)::value;
+          lds_wait<(kp + 1 < NG) ? 8 : 0>(vr[kp % 3][0], vr[kp % 3][1], vr[kp % 3][2], vr[kp % 3][3]);
+          if constexpr (kp + 2 < NG) issue_v(std::integral_constant<int, kp + 2>{});
           const bf16x8 pf = pack8(s[2 * kp], s[2 * kp + 1]);
 #pragma unroll
-          for (int dt = 0; dt < 4; ++dt) {
-            const char* pv = Vs + v_off[dt] + kp * 4096;
-            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)LDS_PTR(pv));
-            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)LDS_PTR(pv + 16 * 128));
-            const bf16x8 vf = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
-            o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, o[dt], 0, 0, 0);
-          }
-        }
+          for (int dt = 0; dt < 4; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vr[kp % 3][dt].get(), pf, o[dt], 0, 0, 0);
+          osum = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pf, osum, 0, 0, 0);
+        });
+        const float sum = osum[0];        // every row of the ones tile holds the sums of its column = this lane's query
         if (q < N) {
           const float inv = 1.f / sum;
           bf16_t* op = out + ((size_t)b * N + q) * D + h * 64 + 4 * fg;
@@ -489,47 +560,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(const bf16_t* __restri
   if (bh >= n_heads) return;
   if (role == 0) attn_bwd_dq_body<NT>(bh, qkv, out, dout, lse, dqkv, N, H);
   else attn_bwd_dkv_body<NT>(bh, qkv, out, dout, lse, dqkv, N, H);
-}
-
-// ---- LDS reads whose position in the instruction stream is fixed by the source --------------------------------------------------------
-// The compiler issues a ds_read just before its first use (it is at the register limit here), so a wave with one partner on its SIMD
-// sits in s_waitcnt for most of every step.  These wrappers are volatile asm: they stay in program order, and the data is only handed
-// to the compiler by lds_wait<N>(...), an s_waitcnt lgkmcnt(N) that is tied ("+v") to the registers it releases.  Rules for the caller:
-// every read issued must be released by a later lds_wait before its register dies, N counts the reads issued after the ones being
-// released (LDS returns in order), and no compiler-generated LDS access may sit between an issue and its release.
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-struct TrPair {
-  u32x2 lo, hi;
-  __device__ __forceinline__ bf16x8 get() const { return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3)); }
-};
-template <int OFF>
-__device__ __forceinline__ void lds_issue_row(uint32_t a, u32x4& v) {
-  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(a), "n"(OFF));
-}
-template <int OFF>
-__device__ __forceinline__ void lds_issue_tr(uint32_t a, TrPair& t) {       // rows r and r + 16 of a transposed 16-bit fragment
-  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(t.lo) : "v"(a), "n"(OFF));
-  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(t.hi) : "v"(a), "n"(OFF + 16 * KV_LD));
-}
-template <int N>
-__device__ __forceinline__ void lds_wait(u32x4& a, u32x4& b, u32x4& c, u32x4& d) {
-  asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N < 15 ? N : 15));   // the counter has 4 bits
-}
-template <int N>
-__device__ __forceinline__ void lds_wait(TrPair& a, TrPair& b, TrPair& c, TrPair& d) {
-  asm volatile("s_waitcnt lgkmcnt(%8)" : "+v"(a.lo), "+v"(a.hi), "+v"(b.lo), "+v"(b.hi), "+v"(c.lo), "+v"(c.hi), "+v"(d.lo), "+v"(d.hi) : "n"(N < 15 ? N : 15));
-}
-__device__ __forceinline__ bf16x8 as_bf(const u32x4& v) { return __builtin_bit_cast(bf16x8, v); }
-__device__ __forceinline__ f32x4 as_f4(const u32x4& v) { return __builtin_bit_cast(f32x4, v); }
-
-template <int... I, class F>
-__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, I...>, F&& f) {
-  (f(std::integral_constant<int, I>{}), ...);
-}
-template <int N, class F>
-__device__ __forceinline__ void static_for(F&& f) {
-  static_for_impl(std::make_integer_sequence<int, N>{}, f);
 }
 
 // The whole backward of one head in one workgroup of 8 waves, persistent over heads (one workgroup per CU).  The two-kernel form above
@@ -852,11 +882,20 @@ extern "C" int dkd_attn_fwd(const void* qkv, void* out, float* lse, int32_t B, i
   }
   if (nt >= 8 && B * H >= 2 * n_cu) {    // enough heads per CU for the double-buffered persistent kernel to pay
     const int smem_ring = 2 * 2 * nt * 16 * 128;
+    // the padding mask rides in the MFMA accumulator when N sits in the last two key tiles of the instantiation (197 / 198 in 14)
+    const int nf = N / 16 >= nt ? nt - 1 : N / 16;
+#define RING_LAUNCH(NF_)                                                                                                             \
+  {                                                                                                                                  \
+    if (int rc = set_smem(attn_fwd_ring_kernel<T, NF_>, smem_ring)) return rc;                                                       \
+    hipLaunchKernelGGL((attn_fwd_ring_kernel<T, NF_>), dim3(n_cu), dim3(512), smem_ring, as_stream(stream), (const bf16_t*)qkv,      \
+                       (bf16_t*)out, lse, N, H, B * H);                                                                              \
+  }
     DISPATCH_NT(nt, {
-      if (int rc = set_smem(attn_fwd_ring_kernel<T>, smem_ring)) return rc;
-      hipLaunchKernelGGL(attn_fwd_ring_kernel<T>, dim3(n_cu), dim3(512), smem_ring, as_stream(stream), (const bf16_t*)qkv, (bf16_t*)out, lse, N,
-                         H, B * H);
+      if (nf == T - 1) RING_LAUNCH(T - 1)
+      else if (nf == T - 2) RING_LAUNCH(T - 2)
+      else RING_LAUNCH(-1)
     });
+#undef RING_LAUNCH
     DKD_CHECK_LAUNCH("attn_fwd_ring");
     return DKD_OK;
   }

@@ -80,6 +80,19 @@ __device__ __forceinline__ float gelu_erf_fast(float x) {
   p = fmaf(p, ax, -1.0001030679e+00f);
   return fmaf(-ax, __builtin_amdgcn_exp2f(p), fmaxf(x, 0.f));
 }
+// The same on two values with the polynomial on packed f32 FMAs (v_pk_fma_f32: two lanes' worth per issue slot).  For epilogues in which
+// no MFMA is in flight -- there the VALU is the only busy pipe and the six Horner steps are 60 % of its instructions.
+__device__ __forceinline__ dkd_f32x2 gelu_erf_fast2(dkd_f32x2 x) {
+  const dkd_f32x2 ax = {fminf(fabsf(x[0]), 6.5f), fminf(fabsf(x[1]), 6.5f)};
+  auto k = [](float c) { return dkd_f32x2{c, c}; };
+  dkd_f32x2 p = __builtin_elementwise_fma(k(1.9976321103e-05f), ax, k(-5.5957009936e-04f));
+  p = __builtin_elementwise_fma(p, ax, k(6.8683694644e-03f));
+  p = __builtin_elementwise_fma(p, ax, k(-5.0240056942e-02f));
+  p = __builtin_elementwise_fma(p, ax, k(-4.6248400028e-01f));
+  p = __builtin_elementwise_fma(p, ax, k(-1.1496221801e+00f));
+  p = __builtin_elementwise_fma(p, ax, k(-1.0001030679e+00f));
+  return dkd_f32x2{fmaf(-ax[0], __builtin_amdgcn_exp2f(p[0]), fmaxf(x[0], 0.f)), fmaf(-ax[1], __builtin_amdgcn_exp2f(p[1]), fmaxf(x[1], 0.f))};
+}
 // gelu'(x) = Phi(x) + x phi(x) with ONE exponential: exp(-x^2/2) serves both the A&S erf tail (q, as in gelu_erf_fast) and phi.
 __device__ __forceinline__ float dgelu_erf_fast(float x) {
   const float ax = fabsf(x);

@@ -236,7 +236,10 @@ __device__ __forceinline__ void nt_epilogue(const DkdGemm& g, const int vec_ok, 
           if (FAST == 4) {
             nt_store16((bf16_t*)g.preact + (size_t)m * g.ldp + n, pack8(v));
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = gelu_erf_fast(v[e]);
+            for (int e = 0; e < 8; e += 2) {
+              const dkd_f32x2 y = gelu_erf_fast2(dkd_f32x2{v[e], v[e + 1]});
+              v[e] = y[0], v[e + 1] = y[1];
+            }
           }
           if (FAST == 5) {
             const f32x8 p = unpack8(pre[s]);
@@ -688,7 +691,10 @@ __global__ __launch_bounds__(128 * WN, WN == 4 ? 1 : 2) void gemm_nt256_kernel(c
             f32x8 v = f32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]} + bias8[jp];
             if (FAST == 2) {
 #pragma unroll
-              for (int e = 0; e < 8; ++e) v[e] = gelu_erf_fast(v[e]);
+              for (int e = 0; e < 8; e += 2) {
+                const dkd_f32x2 y = gelu_erf_fast2(dkd_f32x2{v[e], v[e + 1]});
+                v[e] = y[0], v[e + 1] = y[1];
+              }
             }
             pk[jp] = pack8(v);
           }

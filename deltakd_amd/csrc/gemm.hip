@@ -457,7 +457,7 @@ constexpr uint32_t vmcnt_imm(int n) { return (uint32_t)((n & 15) | ((n >> 4) << 
 // 3 = C(f32) = resid + acc + bias (+ bf16 tap); all with identity row maps -- the two epilogues the teacher's qkv / fc1 use, compiled without the per-vector flag tests, row-map
 // divisions and spilled-SGPR reads of the generic path (they, not the GELU arithmetic, were most of the epilogue's VALU time).
 template <int ABL, int EOPS, int WN, int FAST>
-__global__ __launch_bounds__(128 * WN, WN == 4 ? 1 : 2) void gemm_nt256_kernel(const DkdGemm g, const int n_tiles) {
+__global__ __launch_bounds__(128 * WN, WN == 4 ? 1 : 2) void gemm_nt256_kernel(const DkdGemm g, const int n_tiles_cg) {
   constexpr int BN = 64 * WN, NW = 2 * WN;          // tile columns, waves
   constexpr int WHALF = 16384, UNIT = WHALF + BN * 64, RING = WN == 4 ? 5 : 3;
   constexpr int AP = 8 / WN, PIECES = AP + 2;       // 1-KiB LDS-DMA pieces per wave per unit: A rows, then 2 of W rows
@@ -472,13 +472,31 @@ __global__ __launch_bounds__(128 * WN, WN == 4 ? 1 : 2) void gemm_nt256_kernel(c
   // this block's tiles: XCD x = blockIdx % 8 owns a contiguous chunk of the tile list (its L2 sees neighbouring A panels and all
   // of W); the chunk is dealt round-robin to the XCD's resident blocks
   const int x = blockIdx.x & 7, slot_in_xcd = blockIdx.x >> 3, nslots = gridDim.x >> 3;
-  const int tq = n_tiles >> 3, tr = n_tiles & 7;
-  const int chunk_begin = x < tr ? x * (tq + 1) : tr * (tq + 1) + (x - tr) * tq;
-  const int chunk_cnt = tq + (x < tr ? 1 : 0);
+  // n_tiles_cg = n_tiles | col_groups << 24.  col_groups = 1: the chunk is a range of the row-major tile list (a band of row panels,
+  // ALL column tiles: the XCD's L2 has to hold all of W).  col_groups = 2 / 4: the XCDs form a (8 / col_groups) x col_groups grid and
+  // an XCD owns a band of row panels x 1/col_groups of the column tiles -- for a W that does not fit the 4 MiB L2 beside the A panels
+  // (teacher fc1: 4.7 MB; it was re-fetched from the fabric once per round, 5.8x the algorithmic read traffic).
+  const int n_tiles = n_tiles_cg & 0xFFFFFF, CG = n_tiles_cg >> 24;
+  int chunk_begin, chunk_cnt, sub_cols = 0, sub_row0 = 0, sub_col0 = 0;
+  if (CG <= 1) {
+    const int tq = n_tiles >> 3, tr = n_tiles & 7;
+    chunk_begin = x < tr ? x * (tq + 1) : tr * (tq + 1) + (x - tr) * tq;
+    chunk_cnt = tq + (x < tr ? 1 : 0);
+  } else {
+    const int RG = 8 / CG, rg = x / CG, cg = x % CG, tiles_m = n_tiles / tiles_n;
+    sub_cols = tiles_n / CG;
+    sub_col0 = cg * sub_cols;
+    sub_row0 = (int)((long)rg * tiles_m / RG);
+    chunk_cnt = ((int)((long)(rg + 1) * tiles_m / RG) - sub_row0) * sub_cols;
+    chunk_begin = 0;
+  }
   const int my_tiles = slot_in_xcd < chunk_cnt ? (chunk_cnt - slot_in_xcd + nslots - 1) / nslots : 0;
   if (my_tiles == 0) return;
   const int total_units = my_tiles * P;
-  auto tile_of = [&](int k) { return chunk_begin + slot_in_xcd + k * nslots; };
+  auto tile_of = [&](int k) {
+    const int j = slot_in_xcd + k * nslots;
+    return CG <= 1 ? chunk_begin + j : (sub_row0 + j / sub_cols) * tiles_n + sub_col0 + j % sub_cols;
+  };
 
   // ---- load cursor (runs RING units ahead of the multiply cursor)
   const bf16_t* Ab = (const bf16_t*)g.A;
@@ -1619,7 +1637,12 @@ extern "C" int dkd_gemm_nt(const DkdGemm* gp, void* stream) {
 #ifndef DKD_NT256_ABL
 #define DKD_NT256_ABL 0
 #endif
-    const int n_tiles = cdiv(g.M, 256) * (g.N / 256);
+    // W beyond what an XCD's L2 keeps beside the A panels: split the column tiles over two XCD groups (see the kernel)
+    static const int cg_env = getenv("DKD_NT256_CG") ? atoi(getenv("DKD_NT256_CG")) : 0;
+    const int tn256 = g.N / 256;
+    int cgr = (long)g.N * g.K * 2 > (3L << 20) && tn256 % 2 == 0 ? 2 : 1;
+    if (cg_env > 0 && tn256 % cg_env == 0 && 8 % cg_env == 0) cgr = cg_env;
+    const int n_tiles = (cdiv(g.M, 256) * tn256) | (cgr << 24);
     const dim3 grid(n_cu);               // persistent: one workgroup per CU, tiles dealt per XCD inside the kernel
     // bf16 C and nothing else written or read by the epilogue: 16 stores per wave per tile, counted exactly by the waits
     const bool plain16 = !(g.epi & (DKD_EPI_RESID | DKD_EPI_DGELU | DKD_EPI_OUT_F32)) && !g.tap && !g.preact;

@@ -259,6 +259,30 @@ def test_wide_gemm_ragged_rows(ops, epi):
         assert rel(out[lo:hi], ref) < 1e-2, (epi, lo)
 
 
+def test_wide_gemm_column_groups(ops):
+    """W larger than an XCD's L2 keeps beside the A panels (N K 2 B > 3 MiB, an even number of column tiles): the persistent kernel
+    splits the column tiles over two XCD groups and the row panels over four bands.  66 panels on 4 bands = uneven bands, M not a
+    multiple of 256, every row checked through the row / column checksums of the whole output, slices through the product itself."""
+    M, N, K = 16801, 4096, 768
+    a = rnd(M, K, seed=31).to(BF16)
+    w = rnd(N, K, scale=0.05, seed=32).to(BF16)
+    bias = rnd(N, seed=33)
+    canary = torch.full((M + 8, N), 7.0, device=DEV, dtype=BF16)
+    out = canary[:M]
+    ops.gemm_nt(a, w, out=out, bias=bias)
+    assert torch.all(canary[M:] == 7.0), "rows past M were written"
+    for lo, hi in ((0, 300), (4100, 4400), (8300, 8500), (12500, 12900), (M - 300, M)):      # every row band, both column halves
+        ref = a[lo:hi].float() @ w.float().t() + bias
+        assert rel(out[lo:hi], ref) < 1e-2, lo
+    # a checksum of checksums over ALL tiles: sum_n out[m, n] = a[m] . sum_n w[n] + sum(bias)
+    rows = out.float().sum(1)
+    ref_rows = a.float() @ w.float().sum(0) + bias.sum()
+    assert rel(rows, ref_rows) < 2e-2
+    cols = out.float().sum(0)
+    ref_cols = a.float().sum(0) @ w.float().t() + M * bias
+    assert rel(cols, ref_cols) < 2e-2
+
+
 REAL = {  # kind -> (student, teacher, batch): BASELINE.json configs 2, 4, 3 and 5
     "soft": ("deit_tiny_distilled_patch16_224", "deit_small_distilled_patch16_224", 4),
     "lrkd": ("deit_tiny_patch16_224", "deit_base_distilled_patch16_224", 4),

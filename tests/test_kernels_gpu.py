@@ -243,10 +243,13 @@ def test_attn_fwd_bwd(ops, B, N, H):
         close(d[:, :, i], g[:, :, i], 3e-2, f"d{nm}")
 
 
-@pytest.mark.parametrize("B,N,H", [(48, 198, 12), (200, 197, 3), (70, 130, 8), (40, 256, 16)])
+@pytest.mark.parametrize("B,N,H", [(48, 198, 12), (200, 197, 3), (70, 130, 8), (40, 256, 16), (90, 193, 6), (90, 208, 6), (90, 209, 6),
+                                   (90, 224, 6), (130, 113, 4), (130, 128, 4), (40, 241, 16)])
 def test_attn_fwd_persistent_kernel(ops, B, N, H):
     """>= 2 heads per CU route to the double-buffered persistent forward (LDS-DMA K/V ring, swizzled unpadded rows); odd head
-    counts per workgroup, N on and off a 16-row boundary, the 14- and 16-tile instantiations."""
+    counts per workgroup, N on and off a 16-row boundary, the 8-, 14- and 16-tile instantiations.  The padding mask rides in the MFMA
+    accumulator when N lies in the last two key tiles of the instantiation (one valid key in the partial tile: 193, 209, 113, 241;
+    no partial tile: 208, 224, 128, 256) and is applied with selects otherwise (130)."""
     qkv = rnd(B * N, 3 * H * 64, scale=1.5, seed=22).to(BF16)
     out, lse = ops.attn_fwd(qkv, B, N, H)
     ref, ref_lse = ref_attention(qkv, B, N, H)

@@ -973,20 +973,21 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const bf16_t* __restric
   // conv_hw > 0: weight gradient of a 3 x 3 / pad 1 convolution, tap = blockIdx.z -- the B row paired with reduction index m is the
   // input pixel m + dy * hw + dx when it lies inside the image, zeros otherwise (no im2col matrix); the tap's [N1, N2] block of
   // C = dW[N1][9][N2] starts at column tap * N2
+  const int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
   if (conv_hw > 0) {
-    conv_dy = (int)blockIdx.z / 3 - 1;
-    conv_dx = (int)blockIdx.z % 3 - 1;
-    C += blockIdx.z * N2;
-    if (blockIdx.z != 4) a_colsum = nullptr;
+    conv_dy = bz / 3 - 1;
+    conv_dx = bz % 3 - 1;
+    C += bz * N2;
+    if (bz != 4) a_colsum = nullptr;
   }
   __shared__ __attribute__((aligned(16))) char smem[4 * TN_TILE];  // [buf][A|B] ; reused by the epilogue (33 KiB)
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = w >> 1, wc = w & 1;
   const int tiles2 = (N2 + 127) / 128;
-  int t1 = blockIdx.x / tiles2, t2 = blockIdx.x % tiles2;
+  int t1 = bx / tiles2, t2 = bx % tiles2;
   if (upper_only) {                      // Gram matrix: blockIdx.x enumerates the tile pairs (t1 <= t2) row by row
-    int p = blockIdx.x, row = 0, len = tiles2;
+    int p = bx, row = 0, len = tiles2;
     while (p >= len) {
       p -= len;
       ++row;
@@ -997,16 +998,20 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const bf16_t* __restric
   }
   const int n1_0 = t1 * 128, n2_0 = t2 * 128;
   const int KT_all = (M + 63) / 64;
-  const int kt_begin = blockIdx.y * kt_per_split;
+  const int kt_begin = by * kt_per_split;
   const int kt_end = min(KT_all, kt_begin + kt_per_split);
   if (kt_begin >= kt_end) return;
 
   const int lrow = tid >> 4, lcol = (tid & 15) * 8;  // staging: thread -> (row lrow + 16 c, 8 elements at lcol)
-  s16x8 ra[4], rb[4];
+  // Operand rows travel global -> registers -> LDS.  A 64-row step is ~0.25 us of MFMA work and a loaded HBM round trip 1-2 us, so the
+  // loads run TN_D steps ahead of the multiply in a ring of register sets (one step ahead -- the first version -- left the kernel
+  // waiting for memory most of the time: 450 TFLOP/s on the conv wgrads, 95 us for the LRKD Gram matrix).
+  constexpr int TN_D = 4;
+  s16x8 ra[TN_D][4], rb[TN_D][4];
   // fused bias gradient: column sums of the A operand (dY) ride along in the blocks of the first N2 tile
   const bool do_colsum = a_colsum != nullptr && t2 == 0;
   float csum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  auto gload = [&](int kt) {
+  auto gload = [&](int kt, const int set) {
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       const int m = kt * 64 + lrow + 16 * c;
@@ -1032,21 +1037,21 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const bf16_t* __restric
               if (n2_0 + lcol + e < N2) vb[e] = (short)pb[e];
         }
       }
-      ra[c] = va;
-      rb[c] = vb;
+      ra[set][c] = va;
+      rb[set][c] = vb;
       if (do_colsum) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) csum[e] += __uint_as_float(((uint32_t)(uint16_t)va[e]) << 16);
       }
     }
   };
-  auto lstore = [&](int buf) {
+  auto lstore = [&](int buf, const int set) {
     char* abase = smem + buf * 2 * TN_TILE;
     char* bbase = abase + TN_TILE;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-      *(s16x8*)(abase + (lrow + 16 * c) * TN_LD + lcol * 2) = ra[c];
-      *(s16x8*)(bbase + (lrow + 16 * c) * TN_LD + lcol * 2) = rb[c];
+      *(s16x8*)(abase + (lrow + 16 * c) * TN_LD + lcol * 2) = ra[set][c];
+      *(s16x8*)(bbase + (lrow + 16 * c) * TN_LD + lcol * 2) = rb[set][c];
     }
   };
 
@@ -1060,40 +1065,49 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const bf16_t* __restric
   // k-slot (g, j) of a 32-deep MFMA step holds m = 4g + j (j<4) | 16 + 4g + (j-4): the same permutation for both operands
   const int tr_off = (4 * fg + (i16 >> 2)) * TN_LD + 8 * (i16 & 3);
 
-  gload(kt_begin);
-  lstore(0);
+#pragma unroll
+  for (int d = 0; d < TN_D; ++d)
+    if (kt_begin + d < kt_end) gload(kt_begin + d, d);
+  lstore(0, 0);
   __syncthreads();
-  for (int kt = kt_begin; kt < kt_end; ++kt) {
-    const int cur = (kt - kt_begin) & 1;
-    if (kt + 1 < kt_end) gload(kt + 1);
-    const char* abase = smem + cur * 2 * TN_TILE;
-    const char* bbase = abase + TN_TILE;
+  for (int kb = kt_begin; kb < kt_end; kb += TN_D) {
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      bf16x8 a[4], b[4];
+    for (int d = 0; d < TN_D; ++d) {
+      const int kt = kb + d;
+      if (kt < kt_end) {                 // (uniform)
+        const int cur = (kt - kt_begin) & 1;
+        // set d held step kt, which is in LDS: it takes step kt + TN_D
+        if (kt + TN_D < kt_end) gload(kt + TN_D, d);
+        const char* abase = smem + cur * 2 * TN_TILE;
+        const char* bbase = abase + TN_TILE;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const char* p = abase + ks * 32 * TN_LD + tr_off + (wr * 64 + i * 16) * 2;
-        s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)LDS_PTR(p));
-        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)LDS_PTR(p + 16 * TN_LD));
-        s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-        a[i] = __builtin_bit_cast(bf16x8, v);
+        for (int ks = 0; ks < 2; ++ks) {
+          bf16x8 a[4], b[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const char* p = abase + ks * 32 * TN_LD + tr_off + (wr * 64 + i * 16) * 2;
+            s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)LDS_PTR(p));
+            s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)LDS_PTR(p + 16 * TN_LD));
+            s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            a[i] = __builtin_bit_cast(bf16x8, v);
+          }
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const char* p = bbase + ks * 32 * TN_LD + tr_off + (wc * 64 + j * 16) * 2;
+            s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)LDS_PTR(p));
+            s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)LDS_PTR(p + 16 * TN_LD));
+            s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            b[j] = __builtin_bit_cast(bf16x8, v);
+          }
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        if (kt + 1 < kt_end) lstore(cur ^ 1, (d + 1) % TN_D);
+        __syncthreads();
       }
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const char* p = bbase + ks * 32 * TN_LD + tr_off + (wc * 64 + j * 16) * 2;
-        s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)LDS_PTR(p));
-        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)LDS_PTR(p + 16 * TN_LD));
-        s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-        b[j] = __builtin_bit_cast(bf16x8, v);
-      }
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
     }
-    if (kt + 1 < kt_end) lstore(cur ^ 1);
-    __syncthreads();
   }
 
   float* cs = (float*)smem;
@@ -1778,6 +1792,25 @@ extern "C" int dkd_gemm_tn_group(const DkdTnProblem* probs, int32_t n, void* str
   return DKD_OK;
 }
 
+// M splits of gemm_tn_kernel: the launch is `blocks_per_split x splits` workgroups on 512 slots (2 per CU); its time is
+// rounds x (steps per block + the block's atomic epilogue, worth ~12 steps).  The old rule (ceil(512 / tiles)) put 36 tiles on 540
+// blocks = two rounds, the second 5 % full (768 x 768: 211 -> 184 us).
+static void tn_pick_splits(const int blocks_per_split, const int KT, int& splits, int& per) {
+  const int smax = cdiv(KT, 4) < 64 ? cdiv(KT, 4) : 64;
+  long best = -1;
+  for (int s = 1; s <= (smax < 1 ? 1 : smax); ++s) {
+    const int p = cdiv(KT, s);
+    if (cdiv(KT, p) != s) continue;                      // an empty split
+    const long rounds = cdiv(blocks_per_split * s, 512);
+    const long t = rounds * (p + 12);
+    if (best < 0 || t < best) {
+      best = t;
+      splits = s;
+      per = p;
+    }
+  }
+}
+
 extern "C" int dkd_gemm_tn(const void* A, const void* B, float* C, int32_t M, int32_t N1, int32_t N2, int32_t lda, int32_t ldb,
                            int32_t ldc, DkdRowMap amap, DkdRowMap bmap, float* a_colsum, void* stream) {
   DKD_CHECK_ARG(A && B && C, "gemm_tn: null operand");
@@ -1820,12 +1853,8 @@ extern "C" int dkd_gemm_tn(const void* A, const void* B, float* C, int32_t M, in
     return DKD_OK;
   }
   const int tiles = cdiv(N1, 128) * cdiv(N2, 128);
-  // enough M-splits to fill 256 CUs x 2 blocks, but at least 4 k-tiles per block
-  int splits = cdiv(512, tiles);
-  if (splits > cdiv(KT, 4)) splits = cdiv(KT, 4);
-  if (splits < 1) splits = 1;
-  const int per = cdiv(KT, splits);
-  splits = cdiv(KT, per);
+  int splits = 1, per = KT;
+  tn_pick_splits(tiles, KT, splits, per);
   hipLaunchKernelGGL(gemm_tn_kernel, dim3(tiles, splits), dim3(256), 0, as_stream(stream), (const bf16_t*)A, (const bf16_t*)B, C, M,
                      N1, N2, lda, ldb, ldc, amap, bmap, per, a_colsum, 0);
   DKD_CHECK_LAUNCH("gemm_tn");
@@ -1840,7 +1869,9 @@ extern "C" int dkd_conv3x3_wgrad(const void* dY, const void* X, float* dW, float
   const int M = B * hw * hw, KT = cdiv(M, 64);
   const int tiles = cdiv(Cout, 128) * cdiv(Cin, 128);
   // dW[o][tap][c] += sum_m dY[m][o] * X[m + shift(tap)][c]: one [Cout, Cin] block per tap, the nine taps side by side in ONE launch
-  // (grid.z); ~1500 workgroups in all, so few M-splits (= few atomically added partial tiles) per tap
+  // (grid.z)
+  // ~1500 workgroups in all, so few M-splits (= few atomically added partial tiles) per tap.  (Measured: 3 splits = two full rounds
+  // instead of 5 = 3.2 rounds changes nothing -- the kernel is bound by the fabric traffic of its operand strips, not by rounds.)
   int splits = cdiv(1536, 9 * tiles);
   if (splits > cdiv(KT, 4)) splits = cdiv(KT, 4);
   if (splits < 1) splits = 1;

@@ -166,7 +166,25 @@ template <int BN>
 struct ResidRegs {
   static constexpr int SW = 64 / (256 / (BN / 8));
   f32x4 lo[2][SW], hi[2][SW];
+  uint4 pre[2][SW];                      // FAST 5: the bf16 pre-activation rows of the dGELU epilogue
 };
+template <int BN>
+__device__ __forceinline__ void preact_prefetch(const DkdGemm& g, ResidRegs<BN>& r, const int m0, const int n0, const int tid) {
+  constexpr int TPR = BN / 8, RPP = 256 / TPR, SW = 64 / RPP;
+  const int n = n0 + (tid % TPR) * 8, r0 = tid / TPR;
+#pragma unroll
+  for (int half = 0; half < 2; ++half)
+#pragma unroll
+    for (int s = 0; s < SW; ++s) {
+      const int m = m0 + half * 64 + r0 + RPP * s;
+      r.pre[half][s] = uint4{0u, 0u, 0u, 0u};
+      if (m < g.M && n < g.N) {          // read once, never again: do not let it displace dH / W in the L2
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        const u32x4 t = __builtin_nontemporal_load((const u32x4*)&((const bf16_t*)g.preact)[(size_t)m * g.ldp + n]);
+        r.pre[half][s] = uint4{t.x, t.y, t.z, t.w};
+      }
+    }
+}
 template <int BN>
 __device__ __forceinline__ void resid_prefetch(const DkdGemm& g, ResidRegs<BN>& r, const int m0, const int n0, const int tid) {
   constexpr int TPR = BN / 8, RPP = 256 / TPR, SW = 64 / RPP;
@@ -187,7 +205,7 @@ __device__ __forceinline__ void resid_prefetch(const DkdGemm& g, ResidRegs<BN>& 
 
 template <int BN, int NJ, int FAST>
 __device__ __forceinline__ void nt_epilogue(const DkdGemm& g, const int vec_ok, char* smem, f32x4 (&acc)[4][NJ], const int m0,
-                                            const int n0, const int tid, const int wr, const int wc, const ResidRegs<BN>* pre = nullptr) {
+                                            const int n0, const int tid, const int wr, const int wc, const ResidRegs<BN>* prf = nullptr) {
   const int lane = tid & 63, frow = lane & 15, fg = lane >> 4;
   float* cs = (float*)smem;
   __syncthreads();
@@ -215,16 +233,9 @@ __device__ __forceinline__ void nt_epilogue(const DkdGemm& g, const int vec_ok, 
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
       uint4 pre[SW];
-      if (FAST == 5) {
+      if (FAST == 5) {                   // requested before the K loop (preact_prefetch)
 #pragma unroll
-        for (int s = 0; s < SW; ++s) {
-          const int m = m0 + half * 64 + r0 + RPP * s;
-          if (m < g.M) {                 // read once, never again: do not let it displace dH / W in the L2
-            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-            const u32x4 t = __builtin_nontemporal_load((const u32x4*)&((const bf16_t*)g.preact)[(size_t)m * g.ldp + n]);
-            pre[s] = uint4{t.x, t.y, t.z, t.w};
-          }
-        }
+        for (int s = 0; s < SW; ++s) pre[s] = prf->pre[half][s];
       }
 #pragma unroll
       for (int s = 0; s < SW; ++s) {
@@ -263,8 +274,8 @@ __device__ __forceinline__ void nt_epilogue(const DkdGemm& g, const int vec_ok, 
       f32x4 r0v[SW], r1v[SW];
 #pragma unroll
       for (int s = 0; s < SW; ++s) {
-        r0v[s] = pre->lo[half][s];
-        r1v[s] = pre->hi[half][s];
+        r0v[s] = prf->lo[half][s];
+        r1v[s] = prf->hi[half][s];
       }
 #pragma unroll
       for (int s = 0; s < SW; ++s) {
@@ -397,6 +408,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const DkdGemm g, const 
   // (after the tile has been staged) their round trip was exposed once per tile -- K = 768 is only 12 steps
   ResidRegs<BN> rres;
   if (FAST == 3 || FAST == 7) resid_prefetch<BN>(g, rres, m0, n0, tid);
+  if (FAST == 5) preact_prefetch<BN>(g, rres, m0, n0, tid);
 
   stage(0, 0);
   for (int kt = 0; kt < KT; ++kt) {

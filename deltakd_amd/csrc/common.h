@@ -93,19 +93,32 @@ __device__ __forceinline__ dkd_f32x2 gelu_erf_fast2(dkd_f32x2 x) {
   p = __builtin_elementwise_fma(p, ax, k(-1.0001030679e+00f));
   return dkd_f32x2{fmaf(-ax[0], __builtin_amdgcn_exp2f(p[0]), fmaxf(x[0], 0.f)), fmaf(-ax[1], __builtin_amdgcn_exp2f(p[1]), fmaxf(x[1], 0.f))};
 }
-// gelu'(x) = Phi(x) + x phi(x) with ONE exponential: exp(-x^2/2) serves both the A&S erf tail (q, as in gelu_erf_fast) and phi.
-__device__ __forceinline__ float dgelu_erf_fast(float x) {
-  const float ax = fabsf(x);
-  const float t = __builtin_amdgcn_rcpf(fmaf(0.2316418882f, ax, 1.0f));
-  float p = fmaf(0.5307027145f, t, -0.7265760135f);
-  p = fmaf(p, t, 0.7107068705f);
-  p = fmaf(p, t, -0.142248368f);
-  p = fmaf(p, t, 0.127414796f);
-  const float e = __builtin_amdgcn_exp2f((x * -0.7213475204f) * x);
-  const float q = (p * t) * e;                       // 1 - Phi(|x|)
-  const float cdf = x >= 0.f ? 1.0f - q : q;
-  return fmaf(x * 0.3989422804f, e, cdf);
+// gelu'(x) = Phi(x) + x phi(x) with ONE transcendental.  With a = |x|, e = exp(-a^2 / 2) and Q = 1 - Phi(a):
+//     gelu'(x) = 1/2 + sign(x) (1/2 - e U(a)),     U(a) = Q(a) / e - a / sqrt(2 pi)
+// (gelu'(-x) = 1 - gelu'(x)).  U is smooth (a Mills ratio minus a line), so a degree-6 polynomial weighted by e fits e U to 1.6e-5
+// absolute on [0, 6.5] (tools_dev/fit_gelu.py), two orders below the bf16 rounding of the product it feeds; beyond 6.5 the argument is
+// clamped (e < 7e-10).  The previous form (A&S 7.1.26) needed v_rcp and v_exp plus the case split: 16 VALU + 2 transcendentals per
+// element, which made the dGELU epilogue (64 elements per thread and tile, three K steps of MFMA) VALU-bound.  Two values at a time:
+// the Horner steps are packed f32 FMAs.
+__device__ __forceinline__ dkd_f32x2 dgelu_erf_fast2(dkd_f32x2 x) {
+  const dkd_f32x2 ax = {fminf(fabsf(x[0]), 6.5f), fminf(fabsf(x[1]), 6.5f)};
+  auto k = [](float c) { return dkd_f32x2{c, c}; };
+  dkd_f32x2 u = __builtin_elementwise_fma(k(7.0407724585e-04f), ax, k(-8.0406090368e-03f));
+  u = __builtin_elementwise_fma(u, ax, k(3.9668294313e-02f));
+  u = __builtin_elementwise_fma(u, ax, k(-1.1693547981e-01f));
+  u = __builtin_elementwise_fma(u, ax, k(2.4441981382e-01f));
+  u = __builtin_elementwise_fma(u, ax, k(-7.9715079225e-01f));
+  u = __builtin_elementwise_fma(u, ax, k(4.9998423263e-01f));
+  const dkd_f32x2 a2 = ax * ax;
+  const dkd_f32x2 e = {__builtin_amdgcn_exp2f(a2[0] * -0.7213475204f), __builtin_amdgcn_exp2f(a2[1] * -0.7213475204f)};
+  const dkd_f32x2 t = __builtin_elementwise_fma(-e, u, k(0.5f));            // 1/2 - e U
+  dkd_f32x2 r;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+    r[i] = 0.5f + __uint_as_float(__float_as_uint(t[i]) ^ (__float_as_uint(x[i]) & 0x80000000u));
+  return r;
 }
+__device__ __forceinline__ float dgelu_erf_fast(float x) { return dgelu_erf_fast2(dkd_f32x2{x, x})[0]; }
 __device__ __forceinline__ float dgelu_erf(float x) {
   const float cdf = 0.5f * (1.0f + fast_erf(x * 0.70710678118654752f));
   const float pdf = 0.3989422804014327f * __expf(-0.5f * x * x);

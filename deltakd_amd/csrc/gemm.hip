@@ -255,7 +255,10 @@ __device__ __forceinline__ void nt_epilogue(const DkdGemm& g, const int vec_ok, 
           if (FAST == 5) {
             const f32x8 p = unpack8(pre[s]);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] *= dgelu_erf_fast(p[e]);
+            for (int e = 0; e < 8; e += 2) {
+              const dkd_f32x2 d = dgelu_erf_fast2(dkd_f32x2{p[e], p[e + 1]});
+              v[e] *= d[0], v[e + 1] *= d[1];
+            }
           }
           // forward outputs (qkv, GELU output) stream; a backward result is read again by the very next kernels (dgrad GEMM + wgrad)
           if (FAST == DKD_NT_C_A || FAST == DKD_NT_C_B) nt_store16((bf16_t*)g.C + (size_t)m * g.ldc + n, pack8(v));

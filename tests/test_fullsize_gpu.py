@@ -118,6 +118,30 @@ def test_attention_full_size(ops):
         assert rel(lse[b0:b0 + 2], torch.logsumexp(s, -1)) < 1e-3
 
 
+@pytest.mark.parametrize("H,N", [(3, 197), (12, 198)])
+def test_attention_backward_full_size(ops, H, N):
+    """The per-head persistent backward at the headline's head counts (768 student / 3072 teacher-shaped heads, three resp. twelve
+    passes per workgroup): gradients of the first, a middle and the last images against autograd through the fp32 reference, and
+    linearity in dO over ALL heads (the recomputed probabilities do not depend on dO): bwd(dO1 + dO2) = bwd(dO1) + bwd(dO2)."""
+    qkv = rnd(B * N, 3 * H * 64, scale=1.5, seed=8).to(BF16)
+    out, lse = ops.attn_fwd(qkv, B, N, H)
+    do1 = rnd(B * N, H * 64, seed=9).to(BF16)
+    do2 = rnd(B * N, H * 64, seed=10).to(BF16)
+    g1 = ops.attn_bwd(qkv, out, do1, lse, B, N, H)
+    for b0 in (0, 131, B - 2):
+        sub = qkv.view(B, N, -1)[b0:b0 + 2].reshape(2 * N, -1).float().requires_grad_(True)
+        q, k, v = sub.view(2, N, 3, H, 64).permute(2, 0, 3, 1, 4)
+        o = ((q @ k.transpose(-1, -2)) * 0.125).softmax(-1) @ v
+        o.transpose(1, 2).reshape(2 * N, H * 64).backward(do1.view(B, N, -1)[b0:b0 + 2].reshape(2 * N, -1).float())
+        got = g1.view(B, N, 3, H, 64)[b0:b0 + 2].float()
+        ref = sub.grad.view(2, N, 3, H, 64)
+        for i, nm in enumerate("qkv"):
+            assert rel(got[:, :, i], ref[:, :, i]) < 3e-2, (nm, b0)
+    g2 = ops.attn_bwd(qkv, out, do2, lse, B, N, H)
+    g12 = ops.attn_bwd(qkv, out, (do1.float() + do2.float()).to(BF16), lse, B, N, H)
+    assert rel(g12, g1.float() + g2.float()) < 2e-2          # three bf16 roundings apart
+
+
 @pytest.fixture(scope="module")
 def models():
     from deltakd_amd import vit

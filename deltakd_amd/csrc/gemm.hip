@@ -1616,7 +1616,10 @@ extern "C" int dkd_gemm_nt(const DkdGemm* gp, void* stream) {
   if (g.epi & DKD_EPI_RESID) vec_ok = vec_ok && (g.ldr % 8 == 0) && (((uintptr_t)g.resid & 15) == 0);
   if (g.preact) vec_ok = vec_ok && (g.ldp % 8 == 0) && (((uintptr_t)g.preact & 15) == 0);
   if (g.tap) vec_ok = vec_ok && (g.ldt % 8 == 0) && (((uintptr_t)g.tap & 15) == 0);
-  const bool narrow = (g.N % 128 != 0) && (g.N % 128 <= 64);
+  // 128 x 64 tiles (48 KiB of LDS: three workgroups per CU) also for the two-output GELU epilogue of a short-K GEMM (the student's fc1:
+  // K = 192, 154 MB of stores): measured 46 -> 43 us; the same tiles lose on the dGELU dgrad (56 -> 59) and on K = 768 (128 -> 138)
+  const bool narrow = ((g.N % 128 != 0) && (g.N % 128 <= 64)) ||
+                      (g.N % 64 == 0 && g.K <= 256 && g.epi == (DKD_EPI_BIAS | DKD_EPI_GELU) && g.preact != nullptr);
   const int tiles_m = cdiv(g.M, BM);
   // wide GEMMs with enough 256 x 256 tiles for >= 4 rounds on 256 CUs: qkv / fc1 of the teacher.  (The WN = 2 instance of the
   // kernel -- 256 x 128 tiles, two workgroups per CU -- was measured for the teacher's N = 768 GEMMs: proj 148 us, fc2 353 us

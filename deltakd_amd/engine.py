@@ -16,6 +16,22 @@ from .models import forward_with_features
 from .shims import accuracy
 
 
+# Blocks whose features this repo's DistillationLoss reads, per distillation type (model/loss.py: lrkd uses student_features[0], [1]
+# and [-1]; no feature term for none).  A tap costs a bf16 [M, D] store per block (and its slab), so the loop asks for exactly these;
+# other types and foreign criteria get every block, as the reference's forward_with_features returns them.
+_STUDENT_TAPS = {"none": (), "lrkd": (0, 1, -1)}
+
+
+def _narrow_student_taps(student_model, criterion, args):
+    from .losses import DistillationLoss
+    inner = student_model
+    while not hasattr(inner, "blocks") and hasattr(inner, "module"):
+        inner = inner.module
+    if hasattr(inner, "tap_layers"):
+        kind = str(getattr(args, "distillation_type", "")).lower()
+        inner.tap_layers = _STUDENT_TAPS.get(kind) if isinstance(criterion, DistillationLoss) else None
+
+
 def train_one_epoch(student_model, teacher_model, train_loader, criterion, optimizer, loss_scaler, clip_grad, mixup_fn, model_ema,
                     device, epoch, args):
     student_model.train()
@@ -58,6 +74,7 @@ def train_one_epoch(student_model, teacher_model, train_loader, criterion, optim
             prefetch([b[0] for b in group] if group_size > 1 else group[0][0], args)
         pending.extend(group)
 
+    _narrow_student_taps(student_model, criterion, args)
     start_group()
     while pending:
         samples, targets, original_targets = pending.popleft()

@@ -576,6 +576,7 @@ class VisionTransformer(nn.Module):
             _trunc_normal_(self.dist_token, std=.02)
         self._shadow = Shadow()
         self._keep = None
+        self.tap_layers = None               # blocks whose mlp output forward_with_taps returns (None: all)
         # weights loaded into the fp32 masters (resume / finetune / eval-only use) must reach the bf16 copies the GEMMs read
         self.register_load_state_dict_post_hook(lambda module, incompatible: module._shadow.optimizer_stepped(bf16_fresh=False))
 
@@ -667,7 +668,9 @@ class VisionTransformer(nn.Module):
         return (outs[0] + outs[1]) / 2
 
     def forward_with_taps(self, img, tap_layers=None):
-        x, taps = self.forward_tokens(img, tap_layers)
+        """``tap_layers`` None: the model's ``tap_layers`` attribute (default None = every block, what the reference's
+        forward_with_features returns); the training loop narrows it to the blocks its criterion reads."""
+        x, taps = self.forward_tokens(img, self.tap_layers if tap_layers is None else tap_layers)
         return self.forward_head(x, img.shape[0]), taps
 
     def forward(self, img):

@@ -298,3 +298,27 @@ def test_validate_equals_the_oracle_loop_on_cpu():
     for k in b:
         assert abs(float(a[k]) - b[k]) < 1e-6, (k, a[k], b[k])
     assert not s.training
+
+
+def test_training_loop_narrows_student_taps_to_what_the_criterion_reads():
+    """deltakd_amd.engine: this repo's DistillationLoss reads student_features[0], [1], [-1] for lrkd and none for `none`, so the
+    loop asks the student for exactly those blocks; a foreign criterion (or another type) gets every block, as the reference's
+    forward_with_features returns them."""
+    from types import SimpleNamespace
+    from deltakd_amd import engine
+    from deltakd_amd.losses import DistillationLoss
+
+    class Student:
+        blocks = [None] * 12
+        tap_layers = "unset"
+
+    wrapped = SimpleNamespace(module=Student())                       # a data-parallel style wrapper
+    ours = object.__new__(DistillationLoss)
+    engine._narrow_student_taps(wrapped, ours, SimpleNamespace(distillation_type="lrkd"))
+    assert wrapped.module.tap_layers == (0, 1, -1)
+    engine._narrow_student_taps(wrapped, ours, SimpleNamespace(distillation_type="NONE"))
+    assert wrapped.module.tap_layers == ()
+    engine._narrow_student_taps(wrapped, ours, SimpleNamespace(distillation_type="mgd"))
+    assert wrapped.module.tap_layers is None
+    engine._narrow_student_taps(wrapped, lambda *a: 0, SimpleNamespace(distillation_type="lrkd"))
+    assert wrapped.module.tap_layers is None

@@ -53,39 +53,76 @@ def make_args(cfg, batch, epochs=1):
     return SimpleNamespace(**a)
 
 
-def cpu_baseline(cfg, batch=8, steps=6):
-    """The oracle (CPU restatement of the reference path, fp32, torch CPU threads) timed on this host."""
-    from oracle import loss_ref, vit_ref
-    torch.manual_seed(42)
-    args = make_args(cfg, batch)
-    kind = cfg["distillation_type"]
-    teacher = vit_ref.create_model_ref(cfg["teacher"], 1000, 0.1).eval()
-    student = vit_ref.create_model_ref(cfg["student"], 1000, 0.1).train()
-    loss_ref.attach_aux_ref(student, teacher, kind, args.lrkd_rank)
-    for p in teacher.parameters():
-        p.requires_grad = False
-    crit = loss_ref.DistillationLossRef(loss_ref.SoftTargetCrossEntropyRef(), teacher, kind, args.alpha, args.tau)
-    opt = torch.optim.AdamW(student.parameters(), lr=5e-4, weight_decay=1e-4)
-    x = torch.randn(batch, 3, 224, 224)
-    y = torch.softmax(torch.randn(batch, 1000), 1)
-    draws = {"noise": torch.rand(batch, 196)} if kind == "mgd" else {}
+def _host_cpus():
+    """(usable cpus, model string): the scheduler affinity, cut down by a cgroup CPU quota when there is one."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = max(1, min(n, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return n, model
 
-    def step():
-        if kind in ("soft", "hard"):
-            out, feats = student(x), None
-        else:
-            out, feats = loss_ref.forward_with_features_ref(student, x)
-        loss = crit(x, out, student, feats, y, args, draws)
-        opt.zero_grad()
-        loss.backward()
-        opt.step()
-    step()
-    t0 = time.time()
-    for _ in range(steps):
-        step()
-    dt = time.time() - t0
-    return {"value": batch * steps / dt, "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{steps} steps of batch {batch} (same models, loss and optimizer; fp32 torch CPU, {os.cpu_count()} logical cpus)"}
+
+def cpu_baseline(cfg, batch=32, warmup=2, steps=10, budget_s=75.0):
+    """The oracle (CPU restatement of the reference path, fp32, torch CPU threads) timed on this host: SURVEY.md section 8(d) --
+    batch 32, 2 warm-up + 10 timed steps.  Threads = min(usable cpus, 32), set deliberately (one thread per logical cpu of a
+    256-thread host oversubscribed the box's CPU share and understated the CPU by 10x in round 2).  Stops early after
+    ``budget_s`` seconds of timed steps so that the default bench run stays within minutes; the sample says what was run."""
+    from oracle import loss_ref, vit_ref
+    cpus, model = _host_cpus()
+    threads = int(os.environ.get("DKD_CPU_BASELINE_THREADS", str(max(1, min(cpus, 32)))))
+    prev = torch.get_num_threads()
+    torch.set_num_threads(threads)
+    try:
+        torch.manual_seed(42)
+        args = make_args(cfg, batch)
+        kind = cfg["distillation_type"]
+        teacher = vit_ref.create_model_ref(cfg["teacher"], 1000, 0.1).eval()
+        student = vit_ref.create_model_ref(cfg["student"], 1000, 0.1).train()
+        loss_ref.attach_aux_ref(student, teacher, kind, args.lrkd_rank)
+        for p in teacher.parameters():
+            p.requires_grad = False
+        crit = loss_ref.DistillationLossRef(loss_ref.SoftTargetCrossEntropyRef(), teacher, kind, args.alpha, args.tau)
+        opt = torch.optim.AdamW(student.parameters(), lr=5e-4, weight_decay=1e-4)
+        x = torch.randn(batch, 3, 224, 224)
+        y = torch.softmax(torch.randn(batch, 1000), 1)
+        draws = {"noise": torch.rand(batch, 196)} if kind == "mgd" else {}
+
+        def step():
+            if kind in ("soft", "hard"):
+                out, feats = student(x), None
+            else:
+                out, feats = loss_ref.forward_with_features_ref(student, x)
+            loss = crit(x, out, student, feats, y, args, draws)
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+        for _ in range(warmup):
+            step()
+        t0 = time.time()
+        done = 0
+        while done < steps and (done == 0 or time.time() - t0 < budget_s):
+            step()
+            done += 1
+        dt = time.time() - t0
+    finally:
+        torch.set_num_threads(prev)
+    return {"value": batch * done / dt, "unit": "images/s", "cores": threads, "kind": "port",
+            "sample": f"{warmup} warm-up + {done} timed steps of batch {batch} (same models, loss and optimizer as the GPU step; fp32 "
+                      f"torch CPU, {threads} threads on {cpus} usable of {os.cpu_count()} logical cpus, {model})"}
 
 
 def main():
@@ -178,10 +215,16 @@ def main():
     # Last timed step: HIP events around every NT-GEMM launch (roofline.achieved).  It runs on ONE stream: with the teacher on its
     # side stream two kernels share the CUs and an event pair would time the sharing, not the kernel (rocprofv3's per-kernel
     # durations of a `--no-side-stream` run are the ones to compare with: profiles/).  The step still counts in `value`.
+    # The student's weight gradients also stay on the compute stream in this step (DKD_NO_WGRAD_OVERLAP: dkd_block_bwd then issues
+    # the grouped wgrad launch itself, inside its probe scope), so that `roofline_student` times every launch whose FLOPs it counts.
     side_saved, criterion.teacher_stream = criterion.teacher_stream, None
+    wg_saved = os.environ.get("DKD_NO_WGRAD_OVERLAP")
+    os.environ["DKD_NO_WGRAD_OVERLAP"] = "1"
     ops.probe_begin()
     stats = run(1)
     criterion.teacher_stream = side_saved
+    if wg_saved is None:
+        del os.environ["DKD_NO_WGRAD_OVERLAP"]
     fence()
     dt = time.perf_counter() - t0
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -203,7 +246,8 @@ def main():
     roofline_student = None
     if st_ms > 0:
         roofline_student = {
-            "path": "student block backward (dkd_block_bwd x depth) + fused loss kernels, last timed step, HIP events",
+            "path": "student block backward (dkd_block_bwd x depth, weight gradients included: issued inline on the one stream) + fused "
+                    "loss kernels, last timed step, HIP events",
             "flop": sb[0] + sl[0], "algorithmic_bytes": sb[1] + sl[1], "ms": st_ms, "launch_groups": sb[3] + sl[3],
             "mfma": {"achieved": (sb[0] + sl[0]) / (st_ms * 1e-3) / 1e12, "peak": 2500.0, "unit": "TFLOP/s",
                      "frac": (sb[0] + sl[0]) / (st_ms * 1e-3) / 1e12 / 2500.0},
@@ -214,14 +258,19 @@ def main():
                                   "gbps": sf[1] / (sf[2] * 1e-3) / 1e9 if sf[2] else 0.0},
         }
     achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-    traffic = None
-    tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")     # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this command
+    # HBM-side bytes per launch of the dominant kernel: NOT measured in this run (PMC counters need rocprofv3); read from the committed
+    # summary of the separate `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes of this same command (tools_dev/collect_profiles.sh)
+    traffic, traffic_source = None, None
+    tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if dom and os.path.exists(tfile):
-        traffic = json.load(open(tfile)).get(a.config, {}).get(dom)
+        tj = json.load(open(tfile))
+        traffic = tj.get(a.config, {}).get(dom)
+        traffic_source = {"file": "profiles/pmc_traffic.json", "collected_by": tj.get("_source", "tools_dev/collect_profiles.sh"),
+                          "commit": tj.get("_commit"), "measured_in_this_run": False}
     f_img = 3 * F_FWD[cfg["student"]] + (F_FWD[cfg["teacher"]] if cfg["distillation_type"] != "none" else 0.0)
     ips = world * a.batch * a.steps / dt
     out = {
-        "metric": "images/sec (whole node) DeiT-tiny<-DeiT-base distill, bs=256/GPU", "value": ips, "unit": "images/s",
+        "metric": f"images/sec (whole node) DeiT-tiny<-DeiT-base distill, bs={a.batch}/GPU", "value": ips, "unit": "images/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
         "config": {"workload": f"exp/{a.config}-deit-tiny.sh: {cfg['student']} <- {cfg['teacher']}, {cfg['distillation_type']}, "
@@ -230,12 +279,29 @@ def main():
                    "model_flops_per_image": f_img, "step_mfma_frac_of_2.5PF": ips * f_img / (world * 2.5e15),
                    "train_loss": stats.get("train_loss")},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": 2500.0, "unit": "TFLOP/s", "frac": achieved / 2500.0,
-                     "traffic": traffic, "kernel": dom, "launches": launches, "avg_launch_us": ms / max(launches, 1) * 1e3,
+                     "traffic": traffic, "traffic_source": traffic_source, "kernel": dom, "launches": launches, "avg_launch_us": ms / max(launches, 1) * 1e3,
                      "flop_per_launch_avg": flops / max(launches, 1),
                      "other_gemm_kernels": {k: {"tflops": v[0] / (v[1] * 1e-3) / 1e12, "launches": v[2], "sum_ms": v[1]}
                                             for k, v in per.items() if k != dom}},
         "roofline_student": roofline_student,
     }
+    if world > 1:
+        # what proves the communicator: every rank's device (UUID, index, local rank), gathered THROUGH the process group that reduced
+        # the gradients, and the collective library's version
+        props = torch.cuda.get_device_properties(dev)
+        mine = {"rank": rank, "local_rank": int(os.environ.get("LOCAL_RANK", "0")), "device_index": dev.index,
+                "uuid": str(getattr(props, "uuid", "")), "name": props.name, "pci_bus_id": getattr(props, "pci_bus_id", None)}
+        gathered = [None] * world
+        dist.all_gather_object(gathered, mine)
+        try:
+            ccl = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:                       # gloo rehearsal on a build without the binding
+            ccl = None
+        out["comm"] = {"world_size": dist.get_world_size(), "backend": dist.get_backend(), "rccl_version": ccl,
+                       "ranks": gathered, "distinct_devices": len({g["uuid"] or (g["device_index"], g["pci_bus_id"]) for g in gathered}),
+                       "overlapped_grad_buckets": getattr(model, "n_buckets", None),
+                       "allreduce_calls_per_step": getattr(model, "collectives", 0) / max(1, a.steps + a.warmup),
+                       "allreduce_bytes_per_step": getattr(model, "bytes_reduced", 0) / max(1, a.steps + a.warmup)}
     if rank == 0:
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg)

@@ -70,8 +70,14 @@ __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + f
 // 1.1e-5 absolute and < 8e-5 relative everywhere: 25x below the bf16 rounding of the value it feeds.  Beyond 6.5 the argument is
 // clamped (Q < 5e-11).  The previous form (Abramowitz-Stegun 7.1.26: v_rcp + v_exp, both quarter rate) made the teacher's fc1
 // epilogue transcendental-bound: 2 x 128 elements x 16 issue cycles per wave and tile = 3.8 us of its 4.5 us.
+// The clamp is a compare + select, not v_min_f32: IEEE minNum(NaN, 6.5) = 6.5 would turn a NaN pre-activation (an overflow inside the
+// fc1 GEMM) into a finite activation and hide a divergence from the loss; with the select NaN stays NaN through the polynomial.
+__device__ __forceinline__ float clamp_abs65(float x) {
+  const float ax = fabsf(x);
+  return ax > 6.5f ? 6.5f : ax;
+}
 __device__ __forceinline__ float gelu_erf_fast(float x) {
-  const float ax = fminf(fabsf(x), 6.5f);
+  const float ax = clamp_abs65(x);
   float p = fmaf(1.9976321103e-05f, ax, -5.5957009936e-04f);
   p = fmaf(p, ax, 6.8683694644e-03f);
   p = fmaf(p, ax, -5.0240056942e-02f);
@@ -83,7 +89,7 @@ __device__ __forceinline__ float gelu_erf_fast(float x) {
 // The same on two values with the polynomial on packed f32 FMAs (v_pk_fma_f32: two lanes' worth per issue slot).  For epilogues in which
 // no MFMA is in flight -- there the VALU is the only busy pipe and the six Horner steps are 60 % of its instructions.
 __device__ __forceinline__ dkd_f32x2 gelu_erf_fast2(dkd_f32x2 x) {
-  const dkd_f32x2 ax = {fminf(fabsf(x[0]), 6.5f), fminf(fabsf(x[1]), 6.5f)};
+  const dkd_f32x2 ax = {clamp_abs65(x[0]), clamp_abs65(x[1])};
   auto k = [](float c) { return dkd_f32x2{c, c}; };
   dkd_f32x2 p = __builtin_elementwise_fma(k(1.9976321103e-05f), ax, k(-5.5957009936e-04f));
   p = __builtin_elementwise_fma(p, ax, k(6.8683694644e-03f));
@@ -101,7 +107,7 @@ __device__ __forceinline__ dkd_f32x2 gelu_erf_fast2(dkd_f32x2 x) {
 // element, which made the dGELU epilogue (64 elements per thread and tile, three K steps of MFMA) VALU-bound.  Two values at a time:
 // the Horner steps are packed f32 FMAs.
 __device__ __forceinline__ dkd_f32x2 dgelu_erf_fast2(dkd_f32x2 x) {
-  const dkd_f32x2 ax = {fminf(fabsf(x[0]), 6.5f), fminf(fabsf(x[1]), 6.5f)};
+  const dkd_f32x2 ax = {clamp_abs65(x[0]), clamp_abs65(x[1])};
   auto k = [](float c) { return dkd_f32x2{c, c}; };
   dkd_f32x2 u = __builtin_elementwise_fma(k(7.0407724585e-04f), ax, k(-8.0406090368e-03f));
   u = __builtin_elementwise_fma(u, ax, k(3.9668294313e-02f));

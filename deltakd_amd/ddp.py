@@ -35,6 +35,8 @@ class DataParallel(nn.Module):
                 shadow.optimizer_stepped(bf16_fresh=False)
         self._done = {}
         self._plan = None
+        self.collectives = 0          # all-reduce calls issued / bytes they carried (bench.py reports them for N > 1)
+        self.bytes_reduced = 0
         if optimizer is not None and hasattr(optimizer, "grad_sync"):
             optimizer.grad_sync = self._sync_flat
         self.overlap = overlap and self.world > 1 and optimizer is not None and hasattr(optimizer, "flat_grads")
@@ -60,6 +62,13 @@ class DataParallel(nn.Module):
     def _reduce(self, t):
         dist.all_reduce(t, group=self.group)
         t.div_(self.world)
+        self.collectives += 1
+        self.bytes_reduced += t.numel() * t.element_size()
+
+    @property
+    def n_buckets(self):
+        """Buckets reduced from the block-backward callback (overlapped); the rest goes out in the tail sync."""
+        return len(self._plan) if self._plan else 0
 
     def _plan_overlap(self, blocks_per_bucket=4):
         """Buckets of consecutive transformer blocks, as index ranges of the optimizer's flat gradient buffers.  A bucket is

@@ -22,14 +22,23 @@ from .shims import accuracy
 _STUDENT_TAPS = {"none": (), "lrkd": (0, 1, -1)}
 
 
-def _narrow_student_taps(student_model, criterion, args):
+def _narrow_student_taps(student_model, criterion):
+    """Narrow the student's taps to what THIS criterion reads (its own ``distillation_type`` -- or a ``student_taps`` attribute a
+    subclass may set -- not the args': the two can differ).  Returns (model, previous setting) for the caller to restore, or None."""
     from .losses import DistillationLoss
     inner = student_model
     while not hasattr(inner, "blocks") and hasattr(inner, "module"):
         inner = inner.module
-    if hasattr(inner, "tap_layers"):
-        kind = str(getattr(args, "distillation_type", "")).lower()
-        inner.tap_layers = _STUDENT_TAPS.get(kind) if isinstance(criterion, DistillationLoss) else None
+    if not hasattr(inner, "tap_layers") or not isinstance(criterion, DistillationLoss):
+        return None
+    taps = getattr(criterion, "student_taps", None)
+    if taps is None:
+        taps = _STUDENT_TAPS.get(str(criterion.distillation_type).lower())
+    if taps is None:
+        return None
+    prev = inner.tap_layers
+    inner.tap_layers = tuple(taps)
+    return inner, prev
 
 
 def train_one_epoch(student_model, teacher_model, train_loader, criterion, optimizer, loss_scaler, clip_grad, mixup_fn, model_ema,
@@ -74,44 +83,51 @@ def train_one_epoch(student_model, teacher_model, train_loader, criterion, optim
             prefetch([b[0] for b in group] if group_size > 1 else group[0][0], args)
         pending.extend(group)
 
-    _narrow_student_taps(student_model, criterion, args)
-    start_group()
-    while pending:
-        samples, targets, original_targets = pending.popleft()
+    def _run_steps():
+        while pending:
+            samples, targets, original_targets = pending.popleft()
 
-        # --amp only ever wrapped the student forward in the reference (tools/engine.py:23-34); the HIP path already computes
-        # in bf16 with fp32 accumulation, so the flag changes nothing here.
-        if args.distillation_type.lower() in ['soft', 'hard']:
-            student_logits = student_model(samples)
-            student_feats = None
-        else:
-            student_logits, student_feats = forward_with_features(student_model, samples)
+            # --amp only ever wrapped the student forward in the reference (tools/engine.py:23-34); the HIP path already computes
+            # in bf16 with fp32 accumulation, so the flag changes nothing here.
+            if args.distillation_type.lower() in ['soft', 'hard']:
+                student_logits = student_model(samples)
+                student_feats = None
+            else:
+                student_logits, student_feats = forward_with_features(student_model, samples)
 
-        loss = criterion(samples, student_logits, student_model, student_feats, targets, args)
+            loss = criterion(samples, student_logits, student_model, student_feats, targets, args)
 
-        if prefetch is not None and len(pending) < group_size:
-            start_group()                # between the loss and the backward: the teacher's next group overlaps the student's work
+            if prefetch is not None and len(pending) < group_size:
+                start_group()                # between the loss and the backward: the teacher's next group overlaps the student's work
 
-        if not isinstance(student_logits, torch.Tensor):
-            student_logits, _ = student_logits
-        if mixup_fn is not None:
-            acc1, acc5 = accuracy(student_logits, original_targets, topk=(1, 5))
-        else:
-            acc1, acc5 = accuracy(student_logits, targets, topk=(1, 5))
+            if not isinstance(student_logits, torch.Tensor):
+                student_logits, _ = student_logits
+            if mixup_fn is not None:
+                acc1, acc5 = accuracy(student_logits, original_targets, topk=(1, 5))
+            else:
+                acc1, acc5 = accuracy(student_logits, targets, topk=(1, 5))
 
-        optimizer.zero_grad()
-        is_second_order = hasattr(optimizer, 'is_second_order') and optimizer.is_second_order
-        loss_scaler(loss, optimizer, clip_grad=clip_grad, parameters=student_model.parameters(), create_graph=is_second_order)
+            optimizer.zero_grad()
+            is_second_order = hasattr(optimizer, 'is_second_order') and optimizer.is_second_order
+            loss_scaler(loss, optimizer, clip_grad=clip_grad, parameters=student_model.parameters(), create_graph=is_second_order)
 
-        if model_ema is not None:
-            model_ema.update(student_model)
+            if model_ema is not None:
+                model_ema.update(student_model)
 
-        metric_logger.update(train_loss=loss.detach())
-        metric_logger.update(train_acc1=acc1.detach())
-        metric_logger.update(train_acc5=acc5.detach())
-        metric_logger.update(train_lr=optimizer.param_groups[0]['lr'])
-        if prefetch is None:
-            start_group()
+            metric_logger.update(train_loss=loss.detach())
+            metric_logger.update(train_acc1=acc1.detach())
+            metric_logger.update(train_acc5=acc5.detach())
+            metric_logger.update(train_lr=optimizer.param_groups[0]['lr'])
+            if prefetch is None:
+                start_group()
+
+    narrowed = _narrow_student_taps(student_model, criterion)     # for this epoch only: forward_with_features outside the loop
+    try:                                                          # keeps returning every block, as the reference's does
+        start_group()
+        _run_steps()
+    finally:
+        if narrowed is not None:
+            narrowed[0].tap_layers = narrowed[1]
     return {k: meter.global_avg for k, meter in metric_logger.meters.items()}
 
 

@@ -154,8 +154,23 @@ class LowRankTargets:
     """
     BLOCK = 96
 
-    def __init__(self, cold_iters=16, warm_iters=1, sweeps=12, ritz_sweeps=2):
-        self.cold_iters, self.warm_iters, self.sweeps, self.ritz_sweeps = cold_iters, warm_iters, sweeps, ritz_sweeps
+    def __init__(self, cold_iters=None, warm_iters=None, sweeps=12, ritz_sweeps=None, monitor_every=None, monitor_bound=None):
+        """Defaults: 16 cold power steps, ONE tracking step per batch, at most 2 Jacobi sweeps inside it (what the parity tests pin:
+        tests/test_fullsize_gpu.py::test_lowrank_tracking_at_the_headline_batch).  Overridable per run without touching code:
+        DKD_LRKD_COLD_ITERS / DKD_LRKD_WARM_ITERS / DKD_LRKD_RITZ_SWEEPS, or ``args.lrkd_warm_iters`` / ``args.lrkd_ritz_sweeps``
+        (read by DistillationLoss).  ``monitor_every`` = n > 0 (DKD_LRKD_MONITOR): every n-th call measures the invariant-subspace
+        residual ||G V_k - V_k (V_k^T G V_k)||_F / ||G V_k||_F of the basis just produced (a diagnostic: torch matmuls, one host
+        sync) and, above ``monitor_bound`` (DKD_LRKD_MONITOR_BOUND, default 0.05), re-converges the basis (mode 3 + power steps)."""
+        env = os.environ.get
+        self.cold_iters = int(env("DKD_LRKD_COLD_ITERS", 16)) if cold_iters is None else cold_iters
+        self.warm_iters = int(env("DKD_LRKD_WARM_ITERS", 1)) if warm_iters is None else warm_iters
+        self.ritz_sweeps = int(env("DKD_LRKD_RITZ_SWEEPS", 2)) if ritz_sweeps is None else ritz_sweeps
+        self.monitor_every = int(env("DKD_LRKD_MONITOR", 0)) if monitor_every is None else monitor_every
+        self.monitor_bound = float(env("DKD_LRKD_MONITOR_BOUND", 0.05)) if monitor_bound is None else monitor_bound
+        self.sweeps = sweeps
+        self.calls = 0
+        self.last_residual = None   # per-layer residuals of the last monitored call (python floats)
+        self.reconverged = 0        # how often the monitor had to re-converge the basis
         self.basis = None
         self.ritz = None            # [L, 96] Ritz values of the last call (squared singular values), device tensor
         self._ws, self._ws_key = None, None
@@ -198,7 +213,35 @@ class LowRankTargets:
         if self.ritz is None or self.ritz.shape != (L, b) or self.ritz.device != G.device:
             self.ritz = torch.empty(L, b, device=G.device, dtype=F32)
         ops.lowrank_step(G, V, 1, self._ws, rank=rank, hi=hi, lo=lo, evals=self.ritz, ritz_sweeps=self.ritz_sweeps)
+        self.calls += 1
+        if self.monitor_every > 0 and self.calls % self.monitor_every == 0:
+            self.last_residual = self.residual(G, rank)
+            if max(self.last_residual) > self.monitor_bound:
+                self.reconverged += 1
+                for _ in range(4):
+                    ops.lowrank_step(G, V, 0, self._ws)
+                ops.lowrank_step(G, V, 2, self._ws)
+                ops.lowrank_step(G, V, 3, self._ws, rank=rank, hi=hi, lo=lo, evals=self.ritz)
         return (V, hi, lo) if want_split else V
+
+    @torch.no_grad()
+    def residual(self, G, rank):
+        """Diagnostic (not on the hot path): how far span(V[:, :rank]) is from an invariant subspace of G, per layer:
+        ||G V_k - V_k (V_k^T G V_k)||_F / ||G V_k||_F.  G holds only its upper 128-tiles: the full matrix is rebuilt here."""
+        L, Dt, _ = G.shape
+        T = (Dt + 127) // 128
+        keep = torch.zeros(Dt, Dt, device=G.device, dtype=torch.bool)
+        for i in range(T):
+            keep[i * 128:(i + 1) * 128, i * 128:] = True
+        Gu = torch.where(keep, G, torch.zeros_like(G))
+        diag_blocks = torch.zeros_like(Gu)
+        for i in range(T):
+            diag_blocks[:, i * 128:(i + 1) * 128, i * 128:(i + 1) * 128] = Gu[:, i * 128:(i + 1) * 128, i * 128:(i + 1) * 128]
+        full = Gu + Gu.transpose(1, 2) - diag_blocks
+        Vk = self.basis[:, :, :rank]
+        GV = torch.matmul(full, Vk)
+        R = GV - torch.matmul(Vk, torch.matmul(Vk.transpose(1, 2), GV))
+        return (R.flatten(1).norm(dim=1) / GV.flatten(1).norm(dim=1)).tolist()
 
     @torch.no_grad()
     def __call__(self, taps, npre, rank):
@@ -399,6 +442,10 @@ class DistillationLoss(nn.Module):
             raise ValueError(f"Invalid distillation type: {self.distillation_type}")
 
         rank = getattr(args, "lrkd_rank", 0)
+        for knob in ("warm_iters", "ritz_sweeps"):                 # --lrkd-warm-iters / --lrkd-ritz-sweeps (tools/train.py)
+            v = getattr(args, "lrkd_" + knob, None)
+            if v is not None:
+                setattr(self.lowrank, knob, int(v))
         ahead = self._ahead.pop(id(inputs), None)
         if ahead is not None and ahead[0] is inputs and ahead[1] == kind:
             t_logits, t_taps, lrkd_tgt = ahead[2]

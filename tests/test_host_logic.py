@@ -302,7 +302,8 @@ def test_validate_equals_the_oracle_loop_on_cpu():
 
 def test_training_loop_narrows_student_taps_to_what_the_criterion_reads():
     """deltakd_amd.engine: this repo's DistillationLoss reads student_features[0], [1], [-1] for lrkd and none for `none`, so the
-    loop asks the student for exactly those blocks; a foreign criterion (or another type) gets every block, as the reference's
+    loop asks the student for exactly those blocks -- chosen from the CRITERION's own type (not the args', which may differ), and
+    only for the duration of the epoch; a foreign criterion (or another type) gets every block, as the reference's
     forward_with_features returns them."""
     from types import SimpleNamespace
     from deltakd_amd import engine
@@ -310,15 +311,52 @@ def test_training_loop_narrows_student_taps_to_what_the_criterion_reads():
 
     class Student:
         blocks = [None] * 12
-        tap_layers = "unset"
+        tap_layers = None
+
+    def crit(kind, **kw):
+        c = object.__new__(DistillationLoss)
+        c.__dict__.update(distillation_type=kind, **kw)
+        return c
 
     wrapped = SimpleNamespace(module=Student())                       # a data-parallel style wrapper
-    ours = object.__new__(DistillationLoss)
-    engine._narrow_student_taps(wrapped, ours, SimpleNamespace(distillation_type="lrkd"))
-    assert wrapped.module.tap_layers == (0, 1, -1)
-    engine._narrow_student_taps(wrapped, ours, SimpleNamespace(distillation_type="NONE"))
-    assert wrapped.module.tap_layers == ()
-    engine._narrow_student_taps(wrapped, ours, SimpleNamespace(distillation_type="mgd"))
-    assert wrapped.module.tap_layers is None
-    engine._narrow_student_taps(wrapped, lambda *a: 0, SimpleNamespace(distillation_type="lrkd"))
-    assert wrapped.module.tap_layers is None
+    for kind, want in (("lrkd", (0, 1, -1)), ("NONE", ())):
+        model, prev = engine._narrow_student_taps(wrapped, crit(kind))
+        assert model is wrapped.module and prev is None and wrapped.module.tap_layers == want
+        wrapped.module.tap_layers = prev
+    assert engine._narrow_student_taps(wrapped, crit("mgd")) is None and wrapped.module.tap_layers is None
+    assert engine._narrow_student_taps(wrapped, lambda *a: 0) is None and wrapped.module.tap_layers is None
+    # a subclass that reads other blocks says so
+    engine._narrow_student_taps(wrapped, crit("lrkd", student_taps=(2, 3)))
+    assert wrapped.module.tap_layers == (2, 3)
+
+
+def test_train_one_epoch_restores_the_students_tap_setting():
+    """The narrowing must not outlive the epoch: after train_one_epoch -- also when a step raises -- the model
+    returns every block again to callers outside the loop."""
+    from types import SimpleNamespace
+    import pytest
+    import torch
+    from deltakd_amd import engine
+    from deltakd_amd.losses import DistillationLoss
+
+    class Student(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.blocks = torch.nn.ModuleList()
+            self.tap_layers = None
+            self.seen = []
+
+        def forward_with_taps(self, x):
+            self.seen.append(self.tap_layers)
+            raise RuntimeError("stop here")
+
+    s = Student()
+    crit = object.__new__(DistillationLoss)
+    torch.nn.Module.__init__(crit)
+    crit.distillation_type = "lrkd"
+    # args say `none` (no teacher lookahead), the criterion says lrkd: the taps follow the criterion
+    args = SimpleNamespace(epochs=1, distillation_type="none", print_freq=0, rank=0)
+    with pytest.raises(RuntimeError, match="stop here"):
+        engine.train_one_epoch(s, torch.nn.Identity(), [(torch.zeros(2, 3), torch.zeros(2, dtype=torch.long))], crit, None, None, None,
+                               None, None, "cpu", 0, args)
+    assert s.seen == [(0, 1, -1)] and s.tap_layers is None

@@ -52,6 +52,9 @@ def parse_args(argv=None):
         ("--recount", I, 1), ("--color-jitter", F, 0.3), ("--aa", S, "rand-m9-mstd0.5-inc1"), ("--smoothing", F, 0.1),
         ("--interpolation", S, "bicubic"), ("--checkpoint", S, None), ("--seed", I, 42), ("--device", S, None),
         ("--teacher-checkpoint", S, None), ("--synthetic-batches", I, 0),
+        # not in the reference: accuracy knobs of the LRKD subspace tracker that stands in for its per-batch svd (None = the defaults
+        # of deltakd_amd.losses.LowRankTargets: one tracking step per batch, at most 2 Jacobi sweeps inside it)
+        ("--lrkd-warm-iters", I, None), ("--lrkd-ritz-sweeps", I, None),
     ]
     for flag, ty, default in typed:
         p.add_argument(flag, type=ty, default=default)

@@ -29,6 +29,11 @@ int block_fwd(const DkdBlock& b, void* st) {
   g.epi = DKD_EPI_BIAS | DKD_EPI_RESID | DKD_EPI_OUT_F32; g.bias = b.proj_b;
   g.resid = b.x; g.ldr = D; g.rowscale = b.s1; g.rows_per_sample = b.N;
   TRY(dkd_gemm_nt(&g, st));
+  if (b.fuse_mlp) {                       // LN2 + fc1 + GELU + fc2 + tap + DropPath + residual: one kernel, h stays in registers
+    const bool save = b.pre != nullptr;
+    return dkd_mlp192_fwd(b.x1, b.ln2_w, b.ln2_b, b.eps, b.fc1_w, b.fc1_b, b.fc2_wt, b.fc2_b, b.s2, b.N, b.x2, b.tap, save ? b.y2 : nullptr,
+                          b.pre, save ? b.h : nullptr, b.mean2, b.rstd2, M, Hd, st);
+  }
   TRY(dkd_layernorm_fwd(b.x1, D, ID, b.ln2_w, b.ln2_b, b.y2, b.mean2, b.rstd2, M, D, b.eps, 0, st));
   g = mk(b.y2, b.fc1_w, b.h, M, Hd, D);
   g.epi = DKD_EPI_BIAS | DKD_EPI_GELU; g.bias = b.fc1_b; g.preact = b.pre; g.ldp = Hd;
@@ -47,11 +52,14 @@ extern "C" int dkd_blocks_fwd(const DkdBlock* blocks, int32_t n_blocks, void* st
   for (int i = 0; i < n_blocks; ++i) {
     const DkdBlock& b = blocks[i];
     DKD_CHECK_ARG(b.x && b.x1 && b.x2 && b.y1 && b.qkv && b.o && b.y2 && b.h, "blocks_fwd: block %d has a null buffer", i);
+    DKD_CHECK_ARG(!b.fuse_mlp || (b.D == 192 && b.hidden % 64 == 0 && b.fc2_wt), "blocks_fwd: block %d: fuse_mlp needs D = 192, hidden %% 64 == 0 and fc2_wt", i);
     if (b.pre) {        // training forward (activations saved): probed as a whole for bench.py's student roofline
       const double M = (double)b.B * b.N, D = b.D, Hd = b.hidden;
       const double flops = 2.0 * M * (4.0 * D * D + 2.0 * D * Hd) + 4.0 * (double)b.B * b.N * b.N * D;
       // x in, x1 in+out, x2 out (f32); y1, qkv, o, y2, pre, h written (+ qkv, o, y1, y2, h read back by the next kernel of the chain)
-      const double bytes = M * (D * 4.0 * 4 + (D * 2.0 * (1 + 3 + 1 + 1) + Hd * 2.0 * 2) * 2 + (b.tap ? D * 2.0 : 0.0));
+      // (with fuse_mlp y2 / pre / h are written once and not read back, x1 is read once)
+      const double bytes = b.fuse_mlp ? M * (D * 4.0 * 4 + D * 2.0 * (1 + 3 + 1) * 2 + D * 2.0 + Hd * 2.0 * 2 + (b.tap ? D * 2.0 : 0.0))
+                                      : M * (D * 4.0 * 4 + (D * 2.0 * (1 + 3 + 1 + 1) + Hd * 2.0 * 2) * 2 + (b.tap ? D * 2.0 : 0.0));
       DkdProbeScope probe(5, flops, bytes, as_stream(stream));
       TRY(block_fwd(b, stream));
     } else {
@@ -75,11 +83,19 @@ extern "C" int dkd_block_bwd(const DkdBlock* bp, const DkdBlockGrads* gp, void* 
   const double bwd_bytes = Md * (30.0 * D + 4.0 * Hd + (r.gtap ? 2.0 * D : 0.0));
   DkdProbeScope probe(3, bwd_flops, bwd_bytes, as_stream(st));
   // ---- MLP branch
+  const bool all4 = r.dF2 != nullptr;   // a second [M, D] buffer keeps the MLP branch's dF alive: all four weight gradients go out together
+  DkdGemm g = {};
+  if (b.fuse_mlp) {
+    // scale-cast + dGELU dgrad + fc1 dgrad + LayerNorm backward + the scale-cast that opens the attention branch: one kernel
+    DKD_CHECK_ARG(D == 192 && Hd % 64 == 0 && r.ln_ws && all4, "block_bwd: fuse_mlp needs D = 192, hidden %% 64 == 0, ln_ws and dF2");
+    TRY(dkd_mlp192_bwd(r.g, r.gtap, b.s2, b.s1, b.N, b.pre, b.fc2_wt, b.fc1_w, b.x1, b.ln2_w, b.mean2, b.rstd2, r.dF, r.dH, r.dF2, r.d_ln2_w,
+                       r.d_ln2_b, r.ln_ws, M, Hd, st));
+  } else {
   TRY(dkd_scale_cast_bf16(r.g, D, ID, b.s2, b.N, r.gtap, 0, D, r.dF, D, M, D, st));
-  DkdGemm g = mk(r.dF, b.fc2_wt, r.dH, M, Hd, D);
+  g = mk(r.dF, b.fc2_wt, r.dH, M, Hd, D);
   g.epi = DKD_EPI_DGELU; g.preact = b.pre; g.ldp = Hd;
   TRY(dkd_gemm_nt(&g, st));
-  const bool all4 = r.dF2 != nullptr;   // a second [M, D] buffer keeps the MLP branch's dF alive: all four weight gradients go out together
+  }
   if (!all4) {                          // both MLP weight gradients in one launch (dF is not overwritten before the attention branch)
     const DkdTnProblem w[2] = {{r.dF, b.h, r.d_fc2_w, r.d_fc2_b, M, D, Hd, D, Hd, Hd, ID, ID},
                                {r.dH, b.y2, r.d_fc1_w, r.d_fc1_b, M, Hd, D, Hd, D, D, ID, ID}};
@@ -89,7 +105,9 @@ extern "C" int dkd_block_bwd(const DkdBlock* bp, const DkdBlockGrads* gp, void* 
   // the next branch) as their epilogue -- dT never goes to memory
   const bool fuse_ln = D == 192 && Hd % 64 == 0 && r.ln_ws != nullptr && getenv("DKD_NO_LNBWD_FUSION") == nullptr;
   void* dFa = all4 ? r.dF2 : r.dF;      // gradient w.r.t. the attention branch's output (bf16)
-  if (fuse_ln) {
+  if (b.fuse_mlp) {
+    // (done above)
+  } else if (fuse_ln) {
     TRY(dkd_gemm_nt_lnbwd(r.dH, b.fc1_wt, M, Hd, Hd, Hd, b.x1, D, b.ln2_w, b.mean2, b.rstd2, r.g, D, r.d_ln2_w, r.d_ln2_b, r.ln_ws, dFa, b.s1,
                           b.N, st));
   } else {
@@ -137,7 +155,7 @@ extern "C" int64_t dkd_layernorm_bwd_workspace_bytes(int32_t M, int32_t D) {
 
 extern "C" int64_t dkd_block_fwd_workspace_bytes(int32_t B, int32_t N, int32_t D, int32_t H, int32_t hidden, int32_t training,
                                                  int32_t with_tap, int64_t* bf16_bytes, int64_t* f32_bytes) {
-  const int64_t M = (int64_t)B * N;
+  const int64_t M = ((int64_t)B * N + 15) / 16 * 16;      // rows in whole groups of 16: what the fused MLP kernels store (DkdBlock.fuse_mlp)
   int64_t b16, f32 = 0;
   if (training) {
     b16 = al256(M * D * 2) * 3 + al256(M * 3 * D * 2) + al256(M * hidden * 2) * 2 + (with_tap ? al256(M * D * 2) : 0);
@@ -151,14 +169,14 @@ extern "C" int64_t dkd_block_fwd_workspace_bytes(int32_t B, int32_t N, int32_t D
 }
 
 extern "C" int64_t dkd_block_bwd_workspace_bytes(int32_t B, int32_t N, int32_t D, int32_t hidden) {
-  const int64_t M = (int64_t)B * N;
+  const int64_t M = ((int64_t)B * N + 15) / 16 * 16;
   return al256(M * D * 2) * 3 + al256(M * hidden * 2) + al256(M * 3 * D * 2) + dkd_layernorm_bwd_workspace_bytes((int32_t)M, D);
 }
 
 extern "C" int dkd_block_bwd_workspace_carve(void* ws, int32_t B, int32_t N, int32_t D, int32_t hidden, DkdBlockGrads* gr) {
   DKD_CHECK_ARG(ws && gr && B > 0 && N > 0 && D > 0 && hidden > 0, "block_bwd_workspace_carve: bad arguments");
   DKD_CHECK_ARG(((uintptr_t)ws & 255) == 0, "block_bwd_workspace_carve: the workspace must be 256-byte aligned");
-  const int64_t M = (int64_t)B * N;
+  const int64_t M = ((int64_t)B * N + 15) / 16 * 16;
   char* p = (char*)ws;
   gr->dF = p;      p += al256(M * D * 2);
   gr->dT = p;      p += al256(M * D * 2);

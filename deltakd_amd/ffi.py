@@ -54,7 +54,7 @@ class Block(C.Structure):
                 [(n, C.c_void_p) for n in ("ln1_w", "ln1_b", "ln2_w", "ln2_b", "qkv_b", "proj_b", "fc1_b", "fc2_b",
                                            "qkv_w", "proj_w", "fc1_w", "fc2_w", "qkv_wt", "proj_wt", "fc1_wt", "fc2_wt",
                                            "s1", "s2", "x", "x1", "x2", "y1", "qkv", "o", "y2", "pre", "h", "tap",
-                                           "mean1", "rstd1", "mean2", "rstd2", "lse")])
+                                           "mean1", "rstd1", "mean2", "rstd2", "lse")] + [("fuse_mlp", C.c_int32)])
 
 
 class BlockGrads(C.Structure):
@@ -87,6 +87,12 @@ _SIGS = {
     "dkd_gemm_nt_lnbwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p,
                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                     C.c_int32, C.c_void_p]),
+    "dkd_mlp192_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                 C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
+                                 C.c_int32, C.c_void_p]),
+    "dkd_mlp192_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                 C.c_int32, C.c_int32, C.c_void_p]),
     "dkd_im2col_patches": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "dkd_prefix_tokens_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "dkd_embed_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),

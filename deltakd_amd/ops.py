@@ -182,6 +182,45 @@ def gemm_nt_lnbwd(a, w, x, gamma, mean, rstd, dx, dgamma, dbeta, ws, *, cast_out
     return dx
 
 
+def mlp192_fwd(x1, ln_w, ln_b, fc1_w, fc1_b, fc2_wt, fc2_b, *, eps=1e-6, rowscale=None, rows_per_sample=0, want_tap=False, save=True,
+               out=None):
+    """The fused MLP branch of a D = 192 block (include/dkd.h, dkd_mlp192_fwd).  x1 f32 [M, 192]; fc1_w / fc2_wt bf16 [hidden, 192].
+    -> dict(x2, tap, y2, pre, h, mean, rstd): y2 / h padded to a multiple of 16 rows, ``pre`` opaque (fragment-native, for mlp192_bwd)."""
+    M, D = x1.shape
+    Hd = fc1_w.shape[0]
+    assert D == 192 and x1.dtype == F32 and x1.is_contiguous() and fc1_w.dtype == BF16 and fc2_wt.dtype == BF16
+    assert fc1_w.shape == (Hd, D) and fc2_wt.shape == (Hd, D) and fc1_w.is_contiguous() and fc2_wt.is_contiguous()
+    dev, Mp = x1.device, (M + 15) // 16 * 16
+    r = {"x2": torch.empty_like(x1) if out is None else out, "tap": torch.empty(M, D, device=dev, dtype=BF16) if want_tap else None,
+         "y2": None, "pre": None, "h": None, "mean": None, "rstd": None}
+    if save:
+        r.update(y2=torch.empty(Mp, D, device=dev, dtype=BF16), pre=torch.empty(Mp * Hd, device=dev, dtype=BF16),
+                 h=torch.empty(Mp, Hd, device=dev, dtype=BF16), mean=torch.empty(M, device=dev, dtype=F32),
+                 rstd=torch.empty(M, device=dev, dtype=F32))
+    check(lib().dkd_mlp192_fwd(ptr(x1), ptr(ln_w), ptr(ln_b), eps, ptr(fc1_w), ptr(fc1_b), ptr(fc2_wt), ptr(fc2_b), ptr(rowscale),
+                               rows_per_sample, ptr(r["x2"]), ptr(r["tap"]), ptr(r["y2"]), ptr(r["pre"]), ptr(r["h"]), ptr(r["mean"]),
+                               ptr(r["rstd"]), M, Hd, stream()), "mlp192_fwd")
+    return r
+
+
+def mlp192_bwd(g, pre, fc2_wt, fc1_w, x1, ln_w, mean, rstd, d_ln_w, d_ln_b, *, gtap=None, s2=None, s1=None, rows_per_sample=0,
+               want_cast=True):
+    """Backward of mlp192_fwd up to (not including) the two weight gradients (include/dkd.h, dkd_mlp192_bwd).  g f32 [M, 192] is updated in
+    place (+= LayerNorm backward); d_ln_w / d_ln_b are accumulated.  -> (dF bf16 [Mp, 192], dH bf16 [Mp, hidden], cast_out bf16 [M, 192])."""
+    M, D = g.shape
+    Hd = fc1_w.shape[0]
+    assert D == 192 and g.dtype == F32 and g.is_contiguous() and x1.is_contiguous()
+    dev, Mp = g.device, (M + 15) // 16 * 16
+    dF = torch.empty(Mp, D, device=dev, dtype=BF16)
+    dH = torch.empty(Mp, Hd, device=dev, dtype=BF16)
+    cast = torch.empty(M, D, device=dev, dtype=BF16) if want_cast else None
+    ws = torch.empty(lib().dkd_layernorm_bwd_workspace_bytes(M, D), device=dev, dtype=torch.uint8)
+    check(lib().dkd_mlp192_bwd(ptr(g), ptr(gtap), ptr(s2), ptr(s1), rows_per_sample, ptr(pre), ptr(fc2_wt), ptr(fc1_w), ptr(x1), ptr(ln_w),
+                               ptr(mean), ptr(rstd), ptr(dF), ptr(dH), ptr(cast), ptr(d_ln_w), ptr(d_ln_b), ptr(ws), M, Hd, stream()),
+          "mlp192_bwd")
+    return dF, dH, cast
+
+
 def im2col_patches(img, p):
     assert img.dtype == F32 and img.is_contiguous() and img.dim() == 4
     B, Cc, H, W = img.shape

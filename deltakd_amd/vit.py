@@ -279,6 +279,11 @@ def _bytes_al(n_elems, itemsize):
     return (n_elems * itemsize + 255) // 256 * 256
 
 
+def mlp_fusion_enabled(D, hidden):
+    """The fused MLP kernels (csrc/mlp192.hip) take the DeiT-tiny shape; DKD_NO_MLP_FUSION=1 keeps the separate launches (A/B)."""
+    return D == 192 and hidden % 64 == 0 and not os.environ.get("DKD_NO_MLP_FUSION")
+
+
 def _fill_weights(bs: ffi.Block, blk: Block, sh: Shadow, B, N, backward: bool):
     D = blk.norm1.weight.numel()
     bs.B, bs.N, bs.D, bs.H, bs.hidden, bs.eps = B, N, D, blk.attn.num_heads, blk.mlp.fc1.out_features, blk.norm1.eps
@@ -288,6 +293,10 @@ def _fill_weights(bs: ffi.Block, blk: Block, sh: Shadow, B, N, backward: bool):
     bs.qkv_b, bs.proj_b, bs.fc1_b, bs.fc2_b = a.qkv.bias.data_ptr(), a.proj.bias.data_ptr(), m.fc1.bias.data_ptr(), m.fc2.bias.data_ptr()
     bs.qkv_w, bs.proj_w = sh.get(a.qkv.weight).data_ptr(), sh.get(a.proj.weight).data_ptr()
     bs.fc1_w, bs.fc2_w = sh.get(m.fc1.weight).data_ptr(), sh.get(m.fc2.weight).data_ptr()
+    if not backward:                     # (the backward runs on the descriptor the forward filled: the flag is decided once)
+        bs.fuse_mlp = 1 if mlp_fusion_enabled(D, m.fc1.out_features) else 0
+        if bs.fuse_mlp:
+            bs.fc2_wt = sh.get(m.fc2.weight, transposed=True).data_ptr()     # the fused forward reads fc2's weight transposed
     if backward:
         bs.qkv_wt, bs.proj_wt = sh.get(a.qkv.weight, transposed=True).data_ptr(), sh.get(a.proj.weight, transposed=True).data_ptr()
         bs.fc1_wt, bs.fc2_wt = sh.get(m.fc1.weight, transposed=True).data_ptr(), sh.get(m.fc2.weight, transposed=True).data_ptr()
@@ -299,7 +308,8 @@ def _block_forward_train(x, B, N, blk: Block, sh: Shadow, s1, s2, want_tap: bool
     Hd, H = blk.mlp.fc1.out_features, blk.attn.num_heads
     dev = x.device
     # bf16 slab: y1 | qkv | o | y2 | pre | h | tap ; f32 slab: x1 | x2 | mean1 | rstd1 | mean2 | rstd2 | lse
-    sizes16 = [M * D, M * 3 * D, M * D, M * D, M * Hd, M * Hd] + ([M * D] if want_tap else [])
+    Mp = (M + 15) // 16 * 16             # the fused MLP kernels store y2 / pre / h in whole 16-row groups
+    sizes16 = [M * D, M * 3 * D, M * D, Mp * D, Mp * Hd, Mp * Hd] + ([M * D] if want_tap else [])
     off16, tot = [], 0
     for n in sizes16:
         off16.append(tot)

@@ -142,6 +142,24 @@ int dkd_gemm_nt_lnbwd(const void* A, const void* W, int32_t M, int32_t K, int32_
                       const float* gamma, const float* mean, const float* rstd, float* dx, int32_t lddx, float* dgamma, float* dbeta,
                       float* ws, void* cast_out, const float* rowscale, int32_t rows_per_sample, void* stream);
 
+/* The whole MLP branch of a D = 192 block (the DeiT-tiny student; [3P] timm Block: x = x + drop_path(mlp(norm2(x))), whose fc2 output
+ * is the feature model/models.py:185-193 taps) as ONE kernel per direction (csrc/mlp192.hip): the activation between the two GEMMs
+ * stays in registers.
+ *   forward : y2 = LN(x1); pre = y2 W1^T + b1; h = gelu(pre); f = h W2^T + b2; tap = bf16(f); x2 = x1 + rowscale[m / rows_per_sample] f
+ *   backward: dF = bf16(s2 g + gtap); dH = (dF W2) * gelu'(pre); dT = dH W1; g += LN'(dT); d_ln_w / d_ln_b +=; cast_out = bf16(s1 g)
+ * fc1_w bf16 [hidden, 192] (nn.Linear layout), fc2_wt bf16 [hidden, 192] = fc2.weight^T.  hidden % 64 == 0.
+ * Saved activations (forward: all five or none -- none = inference; x2 may then alias x1): y2 bf16 [Mp, 192], h bf16 [Mp, hidden] row-major
+ * with Mp = M rounded up to 16 (the kernels store whole 16-row groups without predicates), mean / rstd f32 [M], and `pre`:
+ * Mp * hidden bf16 in a FRAGMENT-NATIVE order (per 16-row group and 32-unit step, one uint4 per lane) that only dkd_mlp192_bwd reads.
+ * backward: dF bf16 [Mp, 192] and dH bf16 [Mp, hidden] are outputs for the weight-gradient launch (dW2 = dF^T h, dW1 = dH^T y2);
+ * ws: dkd_layernorm_bwd_workspace_bytes(M, 192) bytes.  gtap, s1, s2, cast_out, tap may be NULL. */
+int dkd_mlp192_fwd(const float* x1, const float* ln_w, const float* ln_b, float eps, const void* fc1_w, const float* fc1_b,
+                   const void* fc2_wt, const float* fc2_b, const float* rowscale, int32_t rows_per_sample, float* x2, void* tap, void* y2,
+                   void* pre, void* h, float* mean, float* rstd, int32_t M, int32_t hidden, void* stream);
+int dkd_mlp192_bwd(float* g, const void* gtap, const float* s2, const float* s1, int32_t rows_per_sample, const void* pre,
+                   const void* fc2_wt, const void* fc1_w, const float* x1, const float* ln_w, const float* mean, const float* rstd, void* dF,
+                   void* dH, void* cast_out, float* d_ln_w, float* d_ln_b, float* ws, int32_t M, int32_t hidden, void* stream);
+
 /* ---------------------------------------------------------------- data movement / elementwise */
 /* img f32 [B, C, H, W] -> patches bf16 [B*(H/p)*(W/p), C*p*p] in Conv2d weight order (c, i, j). ([3P] PatchEmbed) */
 int dkd_im2col_patches(const float* img, void* patches, int32_t B, int32_t C, int32_t H, int32_t W, int32_t p, void* stream);
@@ -229,7 +247,7 @@ int dkd_probe_end_ex(int32_t n, double* flops, double* bytes, double* ms, int32_
 
 /* ---------------------------------------------------------------- transformer block drivers (host-side launch sequences) */
 /* One pre-LN ViT block ([3P] timm Block: x = x + dp(attn(ln1 x)); x = x + dp(mlp(ln2 x))) as ONE call: the library issues the
- * 7 (forward) / 15 (backward) kernel launches itself, so the Python host pays one FFI crossing per block instead of one per
+ * 7 (forward; 5 with fuse_mlp) / 8-15 (backward) kernel launches itself, so the Python host pays one FFI crossing per block instead of one per
  * kernel (the step was host-bound at ~570 launches).  All buffers are caller-owned; M = B*N rows.
  * Inference: pass mean/rstd/lse/pre = NULL and x1 = x2 = x (in-place residual stream). */
 typedef struct {
@@ -243,6 +261,10 @@ typedef struct {
   void *y1, *qkv, *o, *y2, *pre, *h; /* bf16: LN1 out [M,D], qkv [M,3D], attention out [M,D], LN2 out, fc1 pre-act, GELU out [M,hidden] */
   void* tap;                         /* bf16 [M, D] feature tap (fc2 output before DropPath/residual) or NULL            */
   float *mean1, *rstd1, *mean2, *rstd2, *lse;   /* saved statistics (f32 [M] x4, [B,H,N]) or NULL                        */
+  int32_t fuse_mlp;                  /* 1: the MLP branch runs on dkd_mlp192_fwd / dkd_mlp192_bwd (D = 192, hidden % 64 == 0, fc2_wt set also in
+                                        the forward; y2 / pre / h and the backward's dF / dH sized for M rounded up to 16 rows -- the workspace
+                                        queries below already are; `pre` is then in that kernel pair's private order).  The caller sets it once:
+                                        the same descriptor goes to the forward and to the backward.                       */
 } DkdBlock;
 
 typedef struct {

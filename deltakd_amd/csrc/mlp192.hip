@@ -26,6 +26,7 @@
 //    128-byte lines through a small per-wave LDS staging buffer, two K steps at a time.  All row-major bf16 outputs are padded to a
 //    multiple of 16 rows so that the stores of the counted region need no predicates.
 #include <type_traits>
+#include <utility>
 #include "common.h"
 
 namespace {
@@ -39,7 +40,9 @@ constexpr int F_STG_GRP = 16 * F_STG_ROW;
 constexpr int F_STG_WAVE = 2 * F_STG_GRP;
 constexpr int F_WAVES = 8;
 constexpr int F_CS = 196;                    // f32 row stride of the epilogue staging (16 rows x 192 per wave)
-constexpr int F_SMEM = F_RING * F_SLOT + F_WAVES * F_STG_WAVE;    // 96 KiB + 36 KiB
+constexpr int F_MAX_HIDDEN = 2048;           // the fc1 bias lives in LDS (a global load inside the loop would drain the DMA ring: see kstep)
+constexpr int F_BIAS_OFF = F_RING * F_SLOT + F_WAVES * F_STG_WAVE;
+constexpr int F_SMEM = F_BIAS_OFF + F_MAX_HIDDEN * 4;             // 96 KiB + 36 KiB + 8 KiB
 static_assert(F_SMEM >= F_WAVES * 16 * F_CS * 4, "epilogue staging must fit");
 static_assert(F_SMEM >= 2 * F_WAVES * F_D * 4, "dgamma / dbeta reduction must fit");
 
@@ -50,6 +53,23 @@ static_assert(F_SMEM >= 2 * F_WAVES * F_D * 4, "dgamma / dbeta reduction must fi
 #define DKD_MLP_ABL 0
 #endif
 constexpr int ABL = DKD_MLP_ABL;
+#if DKD_MLP_ABL & 256
+// bit 256: in-kernel stamps (s_memtime = shader cycles, s_memrealtime = 100 MHz) per wave into a buffer of their own, read back by the
+// dev-only export at the end of this file (tools_dev/mlp192_stamps.py).  Slots: 0 start, 1 after the prologue, 2.. one per K step (taken
+// after the step's barrier), 60 loop end, 61 kernel end, 62 / 63 realtime at start / end.
+__device__ unsigned long long dkd_mlp_stamps[1024 * 8 * 64];
+#define STAMP(slot_)                                                                                          \
+  do {                                                                                                        \
+    if (lane == 0) dkd_mlp_stamps[((size_t)blockIdx.x * 8 + w) * 64 + (slot_)] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
+#define STAMP_RT(slot_)                                                                                           \
+  do {                                                                                                            \
+    if (lane == 0) dkd_mlp_stamps[((size_t)blockIdx.x * 8 + w) * 64 + (slot_)] = __builtin_amdgcn_s_memrealtime(); \
+  } while (0)
+#else
+#define STAMP(slot_) do { } while (0)
+#define STAMP_RT(slot_) do { } while (0)
+#endif
 constexpr uint32_t vm_imm(int n) { return (uint32_t)((n & 15) | ((n >> 4) << 14) | 0x0F70); }   // s_waitcnt vmcnt(n) only
 
 struct Mlp192 {
@@ -82,6 +102,40 @@ __device__ __forceinline__ void nt_store16_(bf16_t* q, const uint4 v) {      // 
   typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
   __builtin_nontemporal_store(u32x4{v.x, v.y, v.z, v.w}, (u32x4*)q);
 }
+
+// Fragment reads are PINNED (volatile asm, program order) and run DEPTH fragments ahead of the MFMAs that consume them: left to itself
+// the compiler (at the register limit here) issues each ds_read right before its first use, and a wave then sits out one LDS round trip
+// per two MFMAs -- the ablation builds showed the MFMA + LDS core alone at 43 of the forward's 77 us.  A read is handed to the compiler
+// by an s_waitcnt lgkmcnt(N) tied ("+v") to its registers; N counts only the pinned reads issued after it (the LDS returns in order:
+// compiler-generated LDS operations in between can only make the wait longer).
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+template <int OFF>
+__device__ __forceinline__ void lds_issue_b128(const uint32_t a, u32x4_t& v) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(a), "n"(OFF));
+}
+template <int OFF>
+__device__ __forceinline__ void lds_issue_tr(const uint32_t a, u32x2_t& lo, u32x2_t& hi) {       // rows r and r + 16
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo) : "v"(a), "n"(OFF));
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(a), "n"(OFF + 16 * 384));
+}
+template <int N>
+__device__ __forceinline__ void lds_release(u32x4_t& v) {
+  asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(v) : "n"(N < 15 ? N : 15));
+}
+template <int N>
+__device__ __forceinline__ void lds_release(u32x2_t& lo, u32x2_t& hi) {
+  asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(lo), "+v"(hi) : "n"(N < 15 ? N : 15));
+}
+template <int... I, class Fn>
+__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, I...>, Fn&& f) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class Fn>
+__device__ __forceinline__ void static_for(Fn&& f) {
+  static_for_impl(std::make_integer_sequence<int, N>{}, f);
+}
+constexpr int F_DEPTH = 4;               // fragments in flight per GEMM
 
 // MODE 0 forward, 1 backward.  SAVE (forward): write y2 / pre / h / mean / rstd (training); false = inference, nothing saved.
 template <int MODE, bool SAVE>
@@ -128,6 +182,16 @@ __global__ __launch_bounds__(512, 2) void mlp192_kernel(const Mlp192 p) {
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(dst), "v"(voff), "s"(wbase) : "memory", "m0");
 #pragma clang diagnostic pop
   };
+
+  STAMP(0);
+  STAMP_RT(62);
+  // forward: the fc1 bias into LDS.  (Read from global memory inside the loop, the compiler's wait for it -- it knows nothing of the
+  // LDS-DMA pieces issued through asm -- was vmcnt(0) right behind the pieces of the step: the whole ring drained once per K step.)
+  if (MODE == 0) {
+    float* bl = (float*)(smem + F_BIAS_OFF);
+    for (int i = tid; i < p.hidden; i += 512) bl[i] = p.b1[i];
+    __builtin_amdgcn_s_waitcnt(0xC07F);    // lgkmcnt(0): written before this wave meets the first barrier
+  }
 
   // ---- prologue: the input operand X^T of each group, in registers (MFMA B layout: lane (row li, k group lg) holds features
   // 32 kk + 8 lg .. + 7 of K step kk)
@@ -207,6 +271,7 @@ __global__ __launch_bounds__(512, 2) void mlp192_kernel(const Mlp192 p) {
     }
   }
 
+  STAMP(1);
   // ---- fragment read addresses (bytes inside a slot)
   // A side: tile t, K step kk: row 16 t + li, logical slot 4 kk + lg -> physical (slot & ~7) | ((slot & 7) ^ ((row >> 1) & 7)); (row >> 1) & 7
   // is the same for both tiles
@@ -273,35 +338,67 @@ __global__ __launch_bounds__(512, 2) void mlp192_kernel(const Mlp192 p) {
     else __builtin_amdgcn_s_waitcnt(vm_imm(2 * PC + 3 * E + H));
     if (!(ABL & 64)) __builtin_amdgcn_s_barrier();   // everybody's pieces of slice s have landed; everybody has left slot (s - 1) & 3
     __builtin_amdgcn_sched_barrier(0);
+    if (s < 56) STAMP(2 + s);
     if (!(ABL & 32)) {
       const int nxt = s + 3 < KSn ? s + 3 : KSn - 1;      // past the end: re-issued into a slot nobody reads (keeps the counts uniform)
 #pragma unroll
       for (int c = 0; c < 3; ++c) piece(c, nxt, (s + 3) & 3);
     }
-    const char* slot = smem + (s & 3) * F_SLOT;
-
-    // GEMM 1, transposed: P^T[tile t][hid 4 lg + r][row li]
+    // GEMM 1, transposed: P^T[tile t][hid 4 lg + r][row li].  Fragment f = 6 t + kk; even / odd kk use the two swizzled slot offsets.
     f32x4 P[2][2];
 #pragma unroll
     for (int rg = 0; rg < 2; ++rg) P[rg][0] = P[rg][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const uint32_t slot_a = lds0 + (s & 3) * F_SLOT;
+    const uint32_t aA0 = slot_a + a_base + a_o0, aA1 = slot_a + a_base + a_o1;
+    uint32_t aB[4];
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int kk = 0; kk < 6; ++kk) {
-        const bf16x8 a = (ABL & 16) ? xt[0][kk] : *(const bf16x8*)(slot + a_base + t * (16 * 384) + (kk >> 1) * 128 + ((kk & 1) ? a_o1 : a_o0));
-#pragma unroll
-        for (int rg = 0; rg < NG; ++rg) {
-          if (ABL & 8) P[rg][t][0] += __builtin_bit_cast(f32x4, a)[kk & 3];
-          else P[rg][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, xt[rg][kk], P[rg][t], 0, 0, 0);
-        }
+    for (int m = 0; m < 4; ++m) aB[m] = slot_a + b_base + b_o4[m];
+    u32x4_t af[F_DEPTH];
+    u32x2_t blo[F_DEPTH], bhi[F_DEPTH];
+    u32x4_t bbq[2];                        // forward: the bias of this step's 2 x 4 hidden units of the lane (pinned LDS reads, oldest)
+    if (MODE == 0) {
+      const uint32_t ab = lds0 + F_BIAS_OFF + (32 * s + 4 * lg) * 4;
+      lds_issue_b128<0>(ab, bbq[0]);
+      lds_issue_b128<64>(ab, bbq[1]);
+    }
+    auto issue_a = [&](auto Fc) {
+      constexpr int f = decltype(Fc)::value, t = f / 6, kk = f % 6;
+      lds_issue_b128<t * (16 * 384) + (kk >> 1) * 128>((kk & 1) ? aA1 : aA0, af[f % F_DEPTH]);
+    };
+    auto issue_b = [&](auto Jc) {
+      constexpr int j = decltype(Jc)::value;
+      lds_issue_tr<(j >> 2) * 128>(aB[j & 3], blo[j % F_DEPTH], bhi[j % F_DEPTH]);
+    };
+    if (!(ABL & 16)) static_for<F_DEPTH>([&](auto f) { issue_a(f); });
+    static_for<12>([&](auto Fc) {
+      constexpr int f = decltype(Fc)::value, t = f / 6, kk = f % 6;
+      constexpr int after = (11 - f) < (F_DEPTH - 1) ? (11 - f) : (F_DEPTH - 1);
+      bf16x8 a;
+      if (ABL & 16) a = xt[0][kk];
+      else {
+        lds_release<after>(af[f % F_DEPTH]);
+        a = __builtin_bit_cast(bf16x8, af[f % F_DEPTH]);
       }
+#pragma unroll
+      for (int rg = 0; rg < NG; ++rg) {
+        if (ABL & 8) P[rg][t][0] += __builtin_bit_cast(f32x4, a)[kk & 3];
+        else P[rg][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, xt[rg][kk], P[rg][t], 0, 0, 0);
+      }
+      if (!(ABL & 16)) {
+        if constexpr (f + F_DEPTH < 12) issue_a(std::integral_constant<int, f + F_DEPTH>{});
+      }
+    });
+    // the first B-side fragments of GEMM 2 are requested now: they arrive under the pointwise arithmetic
+    if (!(ABL & 16)) static_for<F_DEPTH>([&](auto j) { issue_b(j); });
 
     // pointwise step -> the A operand of GEMM 2 (k slots: tile 0 units 4 lg + r, then tile 1)
     bf16x8 hA[2];
     f32x4 bb[2];
-    if (MODE == 0) {
-      bb[0] = *(const f32x4*)(p.b1 + 32 * s + 4 * lg);
-      bb[1] = *(const f32x4*)(p.b1 + 32 * s + 16 + 4 * lg);
+    if (MODE == 0) {                       // (issued before every fragment read of this step: long since returned)
+      lds_release<(ABL & 16) ? 1 : 2 * F_DEPTH + 1>(bbq[0]);
+      lds_release<(ABL & 16) ? 0 : 2 * F_DEPTH>(bbq[1]);
+      bb[0] = __builtin_bit_cast(f32x4, bbq[0]);
+      bb[1] = __builtin_bit_cast(f32x4, bbq[1]);
     }
 #pragma unroll
     for (int rg = 0; rg < NG; ++rg) {
@@ -342,22 +439,24 @@ __global__ __launch_bounds__(512, 2) void mlp192_kernel(const Mlp192 p) {
     if (MODE == 1 && !(ABL & 1)) load_pre(s + 2, par);   // (after the last use of preq[par] above)
 
     // GEMM 2: acc[row 4 lg + r][col 16 j + li] += h[row li][k slots] x Wb[k slots][col]
-#pragma unroll
-    for (int j = 0; j < 12; ++j) {
-      const char* q = slot + b_base + (j >> 2) * 128 + b_o4[j & 3];
+    static_for<12>([&](auto Jc) {
+      constexpr int j = decltype(Jc)::value;
+      constexpr int after = (11 - j) < (F_DEPTH - 1) ? (11 - j) : (F_DEPTH - 1);
       bf16x8 b;
       if (ABL & 16) b = xt[1][j >> 1];
       else {
-        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)LDS_PTR(q));
-        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)LDS_PTR(q + 16 * 384));
-        b = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+        lds_release<2 * after>(blo[j % F_DEPTH], bhi[j % F_DEPTH]);
+        b = __builtin_bit_cast(bf16x8, __builtin_shufflevector(blo[j % F_DEPTH], bhi[j % F_DEPTH], 0, 1, 2, 3));
       }
 #pragma unroll
       for (int rg = 0; rg < NG; ++rg) {
         if (ABL & 8) acc[rg][j][0] += __builtin_bit_cast(f32x4, b)[j & 3] + __builtin_bit_cast(f32x4, hA[rg])[j & 3];
         else acc[rg][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hA[rg], b, acc[rg][j], 0, 0, 0);
       }
-    }
+      if (!(ABL & 16)) {
+        if constexpr (j + F_DEPTH < 12) issue_b(std::integral_constant<int, j + F_DEPTH>{});
+      }
+    });
 
     if (par == 1 && (MODE == 1 || SAVE) && !(ABL & 2)) { // full lines of h / dH: 8 lanes x 16 B per row, 8 rows per store instruction
 #pragma unroll
@@ -384,6 +483,7 @@ __global__ __launch_bounds__(512, 2) void mlp192_kernel(const Mlp192 p) {
   else if (ng == 1) run(std::integral_constant<int, 1>{});
   else run(std::integral_constant<int, 0>{});
 
+  STAMP(60);
   // ---- epilogue: whole rows of the GEMM 2 result, one group at a time through this wave's f32 [16][196] staging
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     // the padding pieces have landed too: the ring becomes staging
   __syncthreads();
@@ -473,6 +573,8 @@ __global__ __launch_bounds__(512, 2) void mlp192_kernel(const Mlp192 p) {
       }
     }
   }
+  STAMP(61);
+  STAMP_RT(63);
   if (MODE == 1) {
     // per-column partial sums of dgamma / dbeta: the 4 row lanes of a wave, then the 8 waves through LDS
 #pragma unroll
@@ -526,7 +628,8 @@ extern "C" int dkd_mlp192_fwd(const float* x1, const float* ln_w, const float* l
                               const void* fc2_wt, const float* fc2_b, const float* rowscale, int32_t rows_per_sample, float* x2, void* tap,
                               void* y2, void* pre, void* h, float* mean, float* rstd, int32_t M, int32_t hidden, void* stream) {
   DKD_CHECK_ARG(x1 && ln_w && ln_b && fc1_w && fc1_b && fc2_wt && fc2_b && x2, "mlp192_fwd: null operand");
-  DKD_CHECK_ARG(M > 0 && hidden > 0 && hidden % 64 == 0, "mlp192_fwd: hidden=%d must be a multiple of 64", hidden);
+  DKD_CHECK_ARG(M > 0 && hidden > 0 && hidden % 64 == 0 && hidden <= F_MAX_HIDDEN, "mlp192_fwd: hidden=%d must be a multiple of 64, <= %d", hidden,
+                F_MAX_HIDDEN);
   DKD_CHECK_ARG(!rowscale || rows_per_sample > 0, "mlp192_fwd: rowscale needs rows_per_sample");
   const bool save = y2 || pre || h || mean || rstd;
   DKD_CHECK_ARG(!save || (y2 && pre && h && mean && rstd), "mlp192_fwd: the saved activations (y2, pre, h, mean, rstd) come all or none");
@@ -576,3 +679,9 @@ extern "C" int dkd_mlp192_bwd(float* g, const void* gtap, const float* s2, const
   DKD_CHECK_LAUNCH("mlp192_bwd");
   return dkd_ln_bwd_reduce(ws, grid, d_ln_w, d_ln_b, F_D, stream);
 }
+
+#if DKD_MLP_ABL & 256
+extern "C" int dkd_mlp192_read_stamps(void* host, int64_t bytes) {
+  return hipMemcpyFromSymbol(host, HIP_SYMBOL(dkd_mlp_stamps), (size_t)bytes, 0, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -2;
+}
+#endif

@@ -56,7 +56,8 @@ def main():
         ops.gemm_nt(y, w1, out=h, bias=b1, gelu=True, preact=pre)
         ops.gemm_nt(h, w2, out=x2, bias=b2, resid=x1, rowscale=sc, rows_per_sample=rps, tap=tap)
     res["fwd_fused_us"] = timeit(fused_fwd)
-    res["fwd_unfused_us"] = timeit(unfused_fwd)
+    only = bool(os.environ.get("MLP_BENCH_FUSED_ONLY"))
+    res["fwd_unfused_us"] = None if only else timeit(unfused_fwd)
     fwd_bytes = M * (D * 4 * 2 + D * 2 * 2 + Hd * 2 * 2)       # x1 in, x2 out, y2 + tap, pre + h
     res["fwd_fused_algorithmic_GBps"] = fwd_bytes / res["fwd_fused_us"] / 1e3
     res["fwd_fused_TFLOPs"] = 4.0 * M * D * Hd / res["fwd_fused_us"] / 1e6
@@ -83,7 +84,8 @@ def main():
         ops.gemm_nt_lnbwd(dH, w1t, x1, ln_w, mean_u, rstd_u, gbuf, d_w, d_b, ws, cast_out=cast, rowscale=s1, rows_per_sample=rps)
     res["bwd_fused_us"] = timeit(fused_bwd)
     gbuf.normal_(generator=g)
-    res["bwd_unfused_us"] = timeit(unfused_bwd)
+    res["bwd_unfused_us"] = None if only else timeit(unfused_bwd)
+    res["lib"] = os.environ.get("DKD_LIB", "default")
     bwd_bytes = M * (D * 4 * 3 + D * 2 * 3 + Hd * 2 * 2)       # g in/out, x1; gtap, dF, cast; pre in, dH out
     res["bwd_fused_algorithmic_GBps"] = bwd_bytes / res["bwd_fused_us"] / 1e3
     res["bwd_fused_TFLOPs"] = 4.0 * M * D * Hd / res["bwd_fused_us"] / 1e6

@@ -123,6 +123,8 @@ _SIGS = {
                                      C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "dkd_dropout_mse": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_int64,
                                   C.c_void_p]),
+    "dkd_saliency_scores": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                      C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "dkd_probe_begin": (C.c_int, []),
     "dkd_probe_end": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int32)]),
     "dkd_probe_end_ex": (C.c_int, [C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int32)]),

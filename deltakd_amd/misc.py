@@ -30,23 +30,29 @@ def random_masking(x, mask_ratio, noise=None):
 
 @torch.no_grad()
 def saliency_scores(student_model, teacher_feat, method, n_prefix=2):
-    """The per-patch score that model/misc.py:38-165 argsorts (lowest scores are KEPT).  teacher_feat: [B, N_t, Dt] incl. prefix."""
+    """The per-patch score that model/misc.py:38-165 argsorts (lowest scores are KEPT).  teacher_feat: [B, N_t, Dt] incl. prefix tokens
+    (the teacher tap as it is: no token is copied out -- the scorer kernel addresses CLS / patch rows of each sample itself).
+    Projections and scores run on libdkd at fp32 accuracy (deltakd_amd.models._project_f32, csrc/saliency.hip)."""
+    from . import ops
+    from .ffi import RowMap
+    from .models import _project_f32
     attn = student_model.saliency_attn
-    t = teacher_feat.float()
-    if method == 1:
-        return attn(t[:, n_prefix:])
-    cls_patch = torch.cat([t[:, :1], t[:, n_prefix:]], dim=1)
-    if method == 2:
-        B, L, D = cls_patch.shape
-        H = attn.num_heads
-        q, k = torch.chunk(attn.qk(cls_patch), 2, dim=-1)
-        q = q.reshape(B, L, H, D // H).permute(0, 2, 1, 3)
-        k = k.reshape(B, L, H, D // H).permute(0, 2, 1, 3)
-        a = ((q[:, :, 0:1] @ k.transpose(-2, -1)) * (D // H) ** -0.5).softmax(dim=-1)
-        return a.mean(dim=1).squeeze(1)[:, 1:]
-    if method == 3:
-        w = attn(cls_patch[:, :1], cls_patch[:, 1:])
-        return w.squeeze(1) if w.dim() == 3 else w
+    B, N, D = teacher_feat.shape
+    H, L = attn.num_heads, N - n_prefix
+    t2 = teacher_feat.reshape(B * N, D)
+    if method in (1, 2):
+        qk = _project_f32(t2, attn.qk)                            # every token once (the prefix rows are simply not addressed)
+        q, k = qk[:, :D], qk[:, D:]
+        if method == 1:                                            # self-attention among the patches, diagonal
+            return ops.saliency_scores(q, k, B=B, L=L, H=H, q_rows_per_sample=N, k_rows_per_sample=N, q_first=n_prefix, k_first=n_prefix,
+                                       diagonal=True)
+        # CLS query against [CLS | patches]; the CLS key takes part in the softmax, the patch columns are the scores
+        return ops.saliency_scores(q, k, B=B, L=L, H=H, q_rows_per_sample=N, k_rows_per_sample=N, q_first=0, k_first=n_prefix, diagonal=False,
+                                   extra_key_row=0)
+    if method == 3:                                                # cross attention: CLS query, patch keys
+        q = _project_f32(t2, attn.q, row_map=RowMap(1, N, 0), M=B)
+        k = _project_f32(t2, attn.k)
+        return ops.saliency_scores(q, k, B=B, L=L, H=H, q_rows_per_sample=1, k_rows_per_sample=N, q_first=0, k_first=n_prefix, diagonal=False)
     raise ValueError(f"Invalid saliency masking method: {method}")
 
 

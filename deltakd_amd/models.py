@@ -57,37 +57,84 @@ class DenoisingNetwork(nn.Module):
                 m.bias.copy_(ref.bias)
 
 
+def _project_f32(x, lin, row_map=None, M=None):
+    """x W^T + b at fp32 accuracy on the bf16 MFMA GEMMs: W = hi + lo (bf16 pair: ~16 significant bits of the fp32 master), two
+    accumulating passes; x likewise when it is not bf16 already (the teacher taps are).  x 2-D [rows, in] -> f32 [M or rows, out].
+    The scorer weights receive no gradient (model/misc.py ranks with them under argsort only), so the split is cached per weight version."""
+    from . import ops
+    w = lin.weight
+    key = (w._version, w.data_ptr())
+    cache = getattr(lin, "_dkd_hilo", None)
+    if cache is None or cache[0] != key:
+        wf = w.detach().float()
+        hi = wf.to(vit.BF16)
+        lo = (wf - hi.float()).to(vit.BF16)
+        cache = (key, hi.contiguous(), lo.contiguous())
+        lin._dkd_hilo = cache
+    _, w_hi, w_lo = cache
+    kw = {} if row_map is None else {"amap": row_map}
+    if x.dtype == vit.BF16:
+        parts = [x.contiguous()]
+    else:
+        xf = x.float()
+        x_hi = xf.to(vit.BF16)
+        parts = [x_hi.contiguous(), (xf - x_hi.float()).to(vit.BF16).contiguous()]
+    out = ops.gemm_nt(parts[0], w_hi, M=M, bias=lin.bias.detach(), out_f32=True, **kw)
+    ops.gemm_nt(parts[0], w_lo, out=out, M=M, accumulate=True, **kw)
+    if len(parts) > 1:
+        ops.gemm_nt(parts[1], w_hi, out=out, M=M, accumulate=True, **kw)
+    return out
+
+
+def _never_trained(module):
+    """Marks a scorer's parameters: the reference builds them with requires_grad = True, but no gradient ever reaches them (they only
+    rank tokens under argsort), so torch.optim.AdamW skips them every step (``if p.grad is None: continue``) -- no update and NO weight
+    decay.  deltakd_amd.optim.FusedAdamW leaves parameters with this mark out of its flat buffers for the same effect (its kernels
+    write into pre-allocated zero-filled gradients, where 'never written' cannot be told from 'zero')."""
+    for p in module.parameters():
+        p.dkd_never_grad = True
+    return module
+
+
 class SimpleAttention(nn.Module):
-    """model/models.py:38-56 (saliency scorer).  Only ever used to RANK tokens (argsort), so it carries no gradient; the
-    [B*196, Dt] x [Dt, 2 Dt] projection is a callable vit.Linear (MFMA GEMM), the per-head softmax over 196 x 196 scores is torch glue."""
+    """model/models.py:38-56 (saliency scorer): head-averaged self-attention weights, their DIAGONAL per token.  Only ever used to RANK
+    tokens (argsort), so it carries no gradient.  The [B N, C] x [C, 2 C] projection runs on the MFMA GEMMs at fp32 accuracy
+    (``_project_f32``), the scores on libdkd's fp32 scorer kernel (csrc/saliency.hip): no torch matmul / softmax."""
 
     def __init__(self, dim, num_heads=8):
         super().__init__()
         self.num_heads, self.scale = num_heads, (dim // num_heads) ** -0.5
         self.qk = _linear_default(dim, dim * 2)
+        _never_trained(self)
 
+    @torch.no_grad()
     def forward(self, x):
+        from . import ops
         B, N, C = x.shape
-        qk = self.qk(x).reshape(B, N, 2, self.num_heads, C // self.num_heads).permute(2, 0, 3, 1, 4)
-        attn = ((qk[0] @ qk[1].transpose(-2, -1)) * self.scale).softmax(dim=-1)
-        return attn.mean(dim=1).diagonal(dim1=-2, dim2=-1)
+        qk = _project_f32(x.reshape(B * N, C), self.qk)
+        return ops.saliency_scores(qk[:, :C], qk[:, C:], B=B, L=N, H=self.num_heads, q_rows_per_sample=N, k_rows_per_sample=N, diagonal=True)
 
 
 class SimpleCrossAttention(nn.Module):
-    """model/models.py:14-35."""
+    """model/models.py:14-35: head-averaged attention weights of the queries on the keys, [B, Nq, Nk]."""
 
     def __init__(self, dim, num_heads=8):
         super().__init__()
         self.num_heads, self.scale = num_heads, (dim // num_heads) ** -0.5
         self.q = _linear_default(dim, dim)
         self.k = _linear_default(dim, dim)
+        _never_trained(self)
 
+    @torch.no_grad()
     def forward(self, x_query, x_key):
+        from . import ops
         B, Nq, C = x_query.shape
         Nk = x_key.shape[1]
-        q = self.q(x_query).reshape(B, Nq, self.num_heads, C // self.num_heads).permute(0, 2, 1, 3)
-        k = self.k(x_key).reshape(B, Nk, self.num_heads, C // self.num_heads).permute(0, 2, 1, 3)
-        return ((q @ k.transpose(-2, -1)) * self.scale).softmax(dim=-1).mean(dim=1)
+        q = _project_f32(x_query.reshape(B * Nq, C), self.q)
+        k = _project_f32(x_key.reshape(B * Nk, C), self.k)
+        rows = [ops.saliency_scores(q, k, B=B, L=Nk, H=self.num_heads, q_rows_per_sample=Nq, k_rows_per_sample=Nk, q_first=i, diagonal=False)
+                for i in range(Nq)]
+        return torch.stack(rows, dim=1)
 
 
 def attach_aux(student, teacher, distillation_type, args=None):

@@ -451,6 +451,18 @@ PROBE_SYMBOLS = ("gemm_nt_kernel<128>", "gemm_nt_kernel<64>", "gemm_nt256_kernel
 PROBE_FAMILIES = PROBE_SYMBOLS + ("student_block_bwd", "loss_kernels", "student_block_fwd")
 
 
+def saliency_scores(q, k, *, B, L, H, q_rows_per_sample, k_rows_per_sample, q_first=0, k_first=0, diagonal=True, extra_key_row=-1):
+    """Head-averaged softmax attention weights of the saliency scorer (include/dkd.h, dkd_saliency_scores): q, k f32 2-D projections
+    (row stride = stride(0); k may be a column slice of the same matrix as q) -> scores f32 [B, L]."""
+    assert q.dtype == F32 and k.dtype == F32 and q.dim() == 2 and k.dim() == 2 and q.stride(1) == 1 and k.stride(1) == 1
+    hd = k.shape[1] // H
+    assert k.shape[1] == H * hd and q.shape[1] == H * hd
+    out = torch.empty(B, L, device=q.device, dtype=F32)
+    check(lib().dkd_saliency_scores(ptr(q), ptr(k), ptr(out), B, L, H, hd, q.stride(0), k.stride(0), q_rows_per_sample, k_rows_per_sample,
+                                    q_first, k_first, 1 if diagonal else 0, extra_key_row, stream()), "saliency_scores")
+    return out
+
+
 def probe_begin():
     """bench.py: start bracketing every NT-GEMM launch with HIP events (recorded inside the library, on the launch stream)."""
     check(lib().dkd_probe_begin(), "probe_begin")

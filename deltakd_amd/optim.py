@@ -49,7 +49,9 @@ class FusedAdamW(torch.optim.Optimizer):
     def _flatten(self):
         bound, bound_params = {}, []
         for group in self.param_groups:
-            ps = [p for p in group["params"] if p.requires_grad]
+            # (dkd_never_grad: parameters no gradient ever reaches -- the saliency scorer -- are skipped like torch.optim.AdamW skips
+            # ``p.grad is None``: no update, no weight decay; they keep their slot in the checkpoint's parameter numbering)
+            ps = [p for p in group["params"] if p.requires_grad and not getattr(p, "dkd_never_grad", False)]
             if not ps:
                 self._flat.append(None)
                 continue

@@ -234,6 +234,18 @@ int dkd_diffkd_prepare(const void* t, int32_t ldt, DkdRowMap tmap, const float* 
 int dkd_dropout_mse(const float* a, const float* t, const float* keep, float keep_scale, float w_over_denom, float* loss, void* da,
                     int64_t n, void* stream);
 
+/* Token scores of the saliency_mgd branch (model/misc.py:38-165; scorers model/models.py:14-56): head-averaged softmax attention
+ * weights of an auxiliary attention, fp32 throughout (they are only ranked).  q, k f32 row-major projections (row strides ldq / ldk
+ * floats, heads side by side: head h = columns [h * head_dim, (h + 1) * head_dim)); sample b's rows start at b * rows_per_sample, its
+ * first query / key row is q_first / k_first.  scores f32 [B, L].
+ *   diagonal = 1 (method 1): L queries x L keys,  scores[b, i] = mean_h softmax_j(q_i . k_j / sqrt(head_dim))[j = i]
+ *   diagonal = 0 (methods 2, 3): ONE query (row q_first) x L keys (+ the key at row extra_key_row of the sample when >= 0, which takes part
+ *                in the softmax but gets no score: the CLS token of method 2),  scores[b, j] = mean_h softmax(...)[j]
+ * L <= 255, head_dim in {16, 32, 48, 64, 96, 128}. */
+int dkd_saliency_scores(const float* q, const float* k, float* scores, int32_t B, int32_t L, int32_t H, int32_t head_dim, int32_t ldq,
+                        int32_t ldk, int64_t q_rows_per_sample, int64_t k_rows_per_sample, int32_t q_first, int32_t k_first,
+                        int32_t diagonal, int32_t extra_key_row, void* stream);
+
 /* Launch probe for bench.py: between begin and end every dkd_gemm_nt launch is bracketed by HIP events recorded on ITS stream.
  * end() synchronises them and returns per kernel symbol (0 = gemm_nt_kernel<128>, 1 = gemm_nt_kernel<64>, 2 = gemm_nt256_kernel)
  * the algorithmic FLOPs (2 M N K), the summed durations (ms) and the launch counts (arrays of 3).  Off by default. */

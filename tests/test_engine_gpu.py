@@ -50,8 +50,8 @@ def _pair(kind, real):
     from deltakd_amd.models import attach_aux
     torch.manual_seed(31)
     if real:
-        t_name = "deit_base_distilled_patch16_224" if kind == "mgd" else "deit_small_distilled_patch16_224"
-        s_name = "deit_tiny_patch16_224" if kind == "mgd" else "deit_tiny_distilled_patch16_224"
+        t_name = "deit_base_distilled_patch16_224" if kind in ("mgd", "lrkd") else "deit_small_distilled_patch16_224"
+        s_name = "deit_tiny_patch16_224" if kind in ("mgd", "lrkd") else "deit_tiny_distilled_patch16_224"
         C, size = 1000, 224
         o_t = vit_ref.create_model_ref(t_name, C, 0.0).eval()
         o_s = vit_ref.create_model_ref(s_name, C, 0.1).train()
@@ -78,21 +78,36 @@ def _pair(kind, real):
     return o_t, o_s, t.to(DEV).eval(), s.to(DEV).train(), args, size, C
 
 
-@pytest.mark.parametrize("kind,real", [("soft", False), ("mgd", False), ("mgd", True)])
-def test_train_one_epoch_matches_the_oracle_loop(kind, real):
+@pytest.mark.parametrize("kind,real,lr", [("soft", False, 2e-4), ("mgd", False, 2e-4), ("mgd", False, 1e-3), ("mgd", True, 2e-4),
+                                          ("lrkd", False, 1e-3), ("lrkd", True, 2e-4)])
+def test_train_one_epoch_matches_the_oracle_loop(kind, real, lr):
     """2 steps, B = 4, mixup/cutmix on (numpy draws replayed from the same seed), DropPath keep masks and masking noise injected
-    per step.  Checked: per-step loss (1e-2), epoch averages of loss / acc1 / acc5 / lr as train_one_epoch returns them, the
-    gradients of the SECOND step (they depend on the first update: 8e-2 per tensor, relative to the tensor's own norm; lr = 2e-4: the
-    first Adam step moves every element by ~lr whatever its gradient, so elements at the bf16 noise level move in random directions and
-    the second step's gradients inherit lr-proportional differences on top of the 6e-2 of a single step), and the weights
-    after two AdamW steps through their update  w2 - w0  (direction cosine >= 0.9 per tensor: an Adam step is ~ lr * sign(g) early on, so
-    elements whose gradient is at the bf16 noise level may flip; the cosine bounds how many)."""
+    per step.  Both loops run ``train_one_epoch`` end to end; the oracle's weights are set to the product's after the first optimizer
+    step, so that the second step is compared AT THE SAME WEIGHTS and every bound below is the single-step bound of the kernels, not a
+    constant tuned to how far two AdamW trajectories drift (round 2 had 8e-2 at lr 2e-4 after 0.0814 was measured at lr 1e-3; the
+    cases now run at both learning rates with the same bounds).  Checked:
+      * per-step loss (1e-2) and the epoch averages of loss / acc1 / acc5 / lr as train_one_epoch returns them;
+      * the gradients of the SECOND step, per tensor relative to the tensor's own norm: 6e-2, the bound every single-step parity test of
+        this repo uses (bf16 operands, fp32 accumulation, against fp32);
+      * both optimizer steps through their updates.  An early Adam step is  -lr g / (|g| + eps)  per element (bias-corrected m / sqrt(v) at
+        step 1), i.e. ~ lr sign(g): elements whose gradient is inside the bf16 noise take a step of random sign on either side, elements
+        well above it must agree.  Noise model: the per-tensor bound says the elementwise error has rms <= 6e-2 rms(g); an element with
+        |g_oracle| >= 0.5 rms(g) is >= 8 sigma from a sign flip, so on those elements >= 99.5 % of the first-step updates must have the
+        oracle's sign (0.5 % slack for heavy-tailed errors), and -- the bound that replaces round 2's cosine >= 0.9 -- the update
+        restricted to them must have cosine >= 0.98 with the oracle's.
+    lrkd (the headline branch, model/loss.py:80-103 via tools/engine.py:47-48; real = DeiT-tiny <- DeiT-base-distilled): the reference
+    takes an exact SVD of each step's teacher taps (model/loss.py:318-326); the oracle's per-step targets are computed first (the
+    teacher is frozen and sees the same mixed batches on both sides) and handed to BOTH loops -- to the product through
+    ``DistillationLoss.injected`` as an iterator, one list of three targets per step -- because the SVD's column signs are arbitrary and
+    the loss is not invariant to them.  How well the product's own tracker approximates these targets is
+    bounded separately (tests/test_fullsize_gpu.py::test_lowrank_tracking_at_the_headline_batch)."""
     from oracle import engine_ref, loss_ref
     from deltakd_amd.engine import train_one_epoch
     from deltakd_amd.losses import DistillationLoss, call_base_loss
     from deltakd_amd.optim import create_optimizer, param_groups_weight_decay
     from deltakd_amd.shims import Mixup, NativeScaler
     o_t, o_s, t, s, args, size, C = _pair(kind, real)
+    args.lr = lr
     B, steps, depth = 4, 2, 12
     g = torch.Generator().manual_seed(77)
     data = [(torch.randn(B, 3, size, size, generator=g), torch.randint(0, C, (B,), generator=g)) for _ in range(steps)]
@@ -100,27 +115,68 @@ def test_train_one_epoch_matches_the_oracle_loop(kind, real):
     P = (size // (16 if real else 8)) ** 2
     noises = [torch.rand(B, P, generator=g) for _ in range(steps)]
     w0 = {n: p.detach().clone() for n, p in o_s.named_parameters()}
+    o_mix = lambda: engine_ref.MixupRef(mixup_alpha=0.8, cutmix_alpha=1.0, label_smoothing=0.1, num_classes=C)   # noqa: E731
 
-    # ---- oracle loop (CPU fp32)
-    o_opt = torch.optim.AdamW(param_groups_weight_decay(o_s, args.weight_decay, o_s.no_weight_decay()), lr=args.lr, weight_decay=0.0)
-    o_crit = loss_ref.DistillationLossRef(loss_ref.call_base_loss_ref(args), o_t, kind, args.alpha, args.tau)
-    np.random.seed(123)
-    o_stats, o_steps = engine_ref.train_one_epoch_ref(
-        o_s, o_t, [(x.clone(), y.clone()) for x, y in data], o_crit, o_opt, None,
-        engine_ref.MixupRef(mixup_alpha=0.8, cutmix_alpha=1.0, label_smoothing=0.1, num_classes=C), 0, args, keep_per_step=keeps,
-        draws_per_step=[{"noise": n} for n in noises])
+    svd_targets = None
+    if kind == "lrkd":                    # the exact-SVD targets of every step, from the mixed batches the loops will see
+        np.random.seed(123)
+        mixer, svd_targets = o_mix(), []
+        with torch.no_grad():
+            for x, y in data:
+                xm, _ = mixer(x.clone(), y.clone())
+                _, tf = loss_ref.forward_with_features_ref(o_t, xm)
+                svd_targets.append([loss_ref.lrkd_targets_ref(tf[b][:, 2:], args.lrkd_rank) for b in (0, 1, 11)])
 
-    # ---- product loop (HIP models, fused losses, FusedAdamW, teacher lookahead on a side stream)
+    # ---- product loop (HIP models, fused losses, FusedAdamW, teacher lookahead on a side stream); weights snapshotted after each step
     opt = create_optimizer(args, s)
     crit = DistillationLoss(call_base_loss(args), t, kind, args.alpha, args.tau, teacher_stream=torch.cuda.Stream())
     crit.injected["noise"] = iter([n.to(DEV) for n in noises])
+    if kind == "lrkd":
+        crit.injected["lrkd_targets"] = iter([[a.to(DEV) for a in tg] for tg in svd_targets])
     s.set_droppath_keep(iter(keeps))
     rec = Recorder(crit)
+    snaps, grads = [], []
+    hip_step = opt.step
+
+    def step_and_snapshot(*a, **k):
+        torch.cuda.synchronize()
+        grads.append({n: p.grad.detach().cpu().clone() for n, p in s.named_parameters() if p.grad is not None})
+        out = hip_step(*a, **k)
+        torch.cuda.synchronize()
+        snaps.append({n: p.detach().cpu().clone() for n, p in s.named_parameters()})
+        return out
+    opt.step = step_and_snapshot
     np.random.seed(123)
     mix = Mixup(mixup_alpha=0.8, cutmix_alpha=1.0, prob=1.0, switch_prob=0.5, label_smoothing=0.1, num_classes=C)
     stats = train_one_epoch(s, t, [(x.clone().to(DEV), y.clone().to(DEV)) for x, y in data], rec, opt, NativeScaler(), None, mix, None,
                             torch.device(DEV), 0, args)
     torch.cuda.synchronize()
+    assert len(snaps) == steps and len(grads) == steps
+
+    # ---- oracle loop (CPU fp32); after ITS first step the weights become the product's
+    class SyncedAdamW(torch.optim.AdamW):
+        calls = 0
+
+        def step(self, closure=None):
+            self.o_grads.append({n: p.grad.detach().clone() for n, p in o_s.named_parameters() if p.grad is not None})
+            super().step(closure)
+            self.o_after.append({n: p.detach().clone() for n, p in o_s.named_parameters()})
+            if self.calls < steps - 1:
+                with torch.no_grad():
+                    for n, p in o_s.named_parameters():
+                        p.copy_(snaps[self.calls][n])
+            self.calls += 1
+
+    o_opt = SyncedAdamW(param_groups_weight_decay(o_s, args.weight_decay, o_s.no_weight_decay()), lr=args.lr, weight_decay=0.0)
+    o_opt.o_grads, o_opt.o_after = [], []
+    o_crit = loss_ref.DistillationLossRef(loss_ref.call_base_loss_ref(args), o_t, kind, args.alpha, args.tau)
+    np.random.seed(123)
+    draws = [{"noise": n} for n in noises]
+    if kind == "lrkd":
+        for d, tg in zip(draws, svd_targets):
+            d["lrkd_targets"] = tg
+    o_stats, o_steps = engine_ref.train_one_epoch_ref(o_s, o_t, [(x.clone(), y.clone()) for x, y in data], o_crit, o_opt, None, o_mix(), 0, args,
+                                                      keep_per_step=keeps, draws_per_step=draws)
 
     hip_steps = [float(v) for v in rec.losses]
     assert len(hip_steps) == steps
@@ -132,24 +188,30 @@ def test_train_one_epoch_matches_the_oracle_loop(kind, real):
     assert abs(float(stats["train_acc1"]) - o_stats["train_acc1"]) <= tol_acc, (stats, o_stats)
     assert abs(float(stats["train_acc5"]) - o_stats["train_acc5"]) <= tol_acc, (stats, o_stats)
 
-    ref = dict(o_s.named_parameters())
-    bad, checked, cos_min = [], 0, 1.0
-    for n, p in s.named_parameters():
-        go = ref[n].grad
-        if go is None or go.norm() == 0 or n.endswith("attn.qkv.bias"):      # key third of qkv.bias: zero in exact arithmetic
-            continue
-        gr = p.grad.detach().cpu()
-        err = (gr - go).norm().item() / go.norm().item()
-        if err > 8e-2:
-            bad.append((n, "step-2 gradient", err))
-        dw_h, dw_o = p.detach().cpu() - w0[n], ref[n].detach() - w0[n]
-        cos = torch.nn.functional.cosine_similarity(dw_h.flatten().double(), dw_o.flatten().double(), dim=0).item()
-        cos_min = min(cos_min, cos)
-        if cos < 0.9:
-            bad.append((n, "update direction", cos))
-        checked += 1
-    assert not bad, (len(bad), bad[:8])
-    assert checked > 100
+    bad, checked, worst_g, worst_cos, worst_sign = [], 0, 0.0, 1.0, 1.0
+    before = [w0, snaps[0]]
+    for step in range(steps):
+        for n, go in o_opt.o_grads[step].items():
+            if go.norm() == 0 or n.endswith("attn.qkv.bias") or n not in grads[step]:     # key third of qkv.bias: zero in exact arithmetic
+                continue
+            err = (grads[step][n] - go).norm().item() / go.norm().item()
+            worst_g = max(worst_g, err)
+            if err > 6e-2:
+                bad.append((n, f"step-{step + 1} gradient", err))
+            # the update of this step, on the elements whose gradient is well above the noise floor
+            live = go.abs() >= 0.5 * go.pow(2).mean().sqrt()
+            if step == 0 and live.sum() >= 16:
+                dw_h, dw_o = (snaps[step][n] - before[step][n])[live], (o_opt.o_after[step][n] - before[step][n])[live]
+                agree = (torch.sign(dw_h) == torch.sign(dw_o)).float().mean().item()
+                cos = torch.nn.functional.cosine_similarity(dw_h.flatten().double(), dw_o.flatten().double(), dim=0).item()
+                worst_sign, worst_cos = min(worst_sign, agree), min(worst_cos, cos)
+                if agree < 0.995:
+                    bad.append((n, "first-step update sign agreement", agree))
+                if cos < 0.98:
+                    bad.append((n, "first-step update direction", cos))
+            checked += 1
+    assert not bad, (len(bad), bad[:8], worst_g, worst_cos, worst_sign)
+    assert checked > 200
 
 
 def test_validate_matches_the_oracle_loop():

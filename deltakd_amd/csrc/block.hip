@@ -20,28 +20,46 @@ DkdGemm mk(const void* A, const void* B, void* C, int M, int N, int K) {
 
 int block_fwd(const DkdBlock& b, void* st) {
   const int M = b.B * b.N, D = b.D, Hd = b.hidden;
-  TRY(dkd_layernorm_fwd(b.x, D, ID, b.ln1_w, b.ln1_b, b.y1, b.mean1, b.rstd1, M, D, b.eps, 0, st));
-  DkdGemm g = mk(b.y1, b.qkv_w, b.qkv, M, 3 * D, D);
+  const int fold = b.pre ? 0 : b.ln_fold;          // LayerNorm folded into the GEMMs around it (inference; include/dkd.h, DkdGemm.xb)
+  DkdGemm g;
+  if (fold & 1) {
+    g = mk(b.xb, b.qkv_w, b.qkv, M, 3 * D, D);
+    g.ln_stats = b.stats1; g.ln_c = b.qkv_c; g.ln_eps = b.eps;
+  } else {
+    TRY(dkd_layernorm_fwd(b.x, D, ID, b.ln1_w, b.ln1_b, b.y1, b.mean1, b.rstd1, M, D, b.eps, 0, st));
+    g = mk(b.y1, b.qkv_w, b.qkv, M, 3 * D, D);
+  }
   g.epi = DKD_EPI_BIAS; g.bias = b.qkv_b;
   TRY(dkd_gemm_nt(&g, st));
   TRY(dkd_attn_fwd(b.qkv, b.o, b.lse, b.B, b.N, b.H, st));
   g = mk(b.o, b.proj_w, b.x1, M, D, D);
   g.epi = DKD_EPI_BIAS | DKD_EPI_RESID | DKD_EPI_OUT_F32; g.bias = b.proj_b;
   g.resid = b.x; g.ldr = D; g.rowscale = b.s1; g.rows_per_sample = b.N;
+  if (fold & 2) {
+    g.xb = b.xb; g.ldxb = D; g.rowstats = b.stats2;
+  }
   TRY(dkd_gemm_nt(&g, st));
   if (b.fuse_mlp) {                       // LN2 + fc1 + GELU + fc2 + tap + DropPath + residual: one kernel, h stays in registers
     const bool save = b.pre != nullptr;
     return dkd_mlp192_fwd(b.x1, b.ln2_w, b.ln2_b, b.eps, b.fc1_w, b.fc1_b, b.fc2_wt, b.fc2_b, b.s2, b.N, b.x2, b.tap, save ? b.y2 : nullptr,
                           b.pre, save ? b.h : nullptr, b.mean2, b.rstd2, M, Hd, st);
   }
-  TRY(dkd_layernorm_fwd(b.x1, D, ID, b.ln2_w, b.ln2_b, b.y2, b.mean2, b.rstd2, M, D, b.eps, 0, st));
-  g = mk(b.y2, b.fc1_w, b.h, M, Hd, D);
+  if (fold & 2) {
+    g = mk(b.xb, b.fc1_w, b.h, M, Hd, D);
+    g.ln_stats = b.stats2; g.ln_c = b.fc1_c; g.ln_eps = b.eps;
+  } else {
+    TRY(dkd_layernorm_fwd(b.x1, D, ID, b.ln2_w, b.ln2_b, b.y2, b.mean2, b.rstd2, M, D, b.eps, 0, st));
+    g = mk(b.y2, b.fc1_w, b.h, M, Hd, D);
+  }
   g.epi = DKD_EPI_BIAS | DKD_EPI_GELU; g.bias = b.fc1_b; g.preact = b.pre; g.ldp = Hd;
   TRY(dkd_gemm_nt(&g, st));
   g = mk(b.h, b.fc2_w, b.x2, M, D, Hd);
   g.epi = DKD_EPI_BIAS | DKD_EPI_RESID | DKD_EPI_OUT_F32; g.bias = b.fc2_b;
   g.resid = b.x1; g.ldr = D; g.rowscale = b.s2; g.rows_per_sample = b.N;
   g.tap = b.tap; g.ldt = D;
+  if (fold & 4) {
+    g.xb = b.xb; g.ldxb = D; g.rowstats = b.stats_next;
+  }
   TRY(dkd_gemm_nt(&g, st));
   return DKD_OK;
 }
@@ -53,6 +71,9 @@ extern "C" int dkd_blocks_fwd(const DkdBlock* blocks, int32_t n_blocks, void* st
     const DkdBlock& b = blocks[i];
     DKD_CHECK_ARG(b.x && b.x1 && b.x2 && b.y1 && b.qkv && b.o && b.y2 && b.h, "blocks_fwd: block %d has a null buffer", i);
     DKD_CHECK_ARG(!b.fuse_mlp || (b.D == 192 && b.hidden % 64 == 0 && b.fc2_wt), "blocks_fwd: block %d: fuse_mlp needs D = 192, hidden %% 64 == 0 and fc2_wt", i);
+    DKD_CHECK_ARG(!b.ln_fold || (!b.pre && !b.fuse_mlp && !b.s1 && !b.s2 && b.xb && (!(b.ln_fold & 1) || (b.stats1 && b.qkv_c)) &&
+                                 (!(b.ln_fold & 2) || (b.stats2 && b.fc1_c)) && (!(b.ln_fold & 4) || b.stats_next)),
+                  "blocks_fwd: block %d: ln_fold is for inference blocks (no saves, no DropPath) and needs xb, the statistics buffers and the row sums", i);
     if (b.pre) {        // training forward (activations saved): probed as a whole for bench.py's student roofline
       const double M = (double)b.B * b.N, D = b.D, Hd = b.hidden;
       const double flops = 2.0 * M * (4.0 * D * D + 2.0 * D * Hd) + 4.0 * (double)b.B * b.N * b.N * D;

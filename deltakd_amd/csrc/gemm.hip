@@ -295,8 +295,25 @@ __device__ __forceinline__ void nt_epilogue(const DkdGemm& g, const int vec_ok, 
             *(f32x4*)cp = r0v[s] + sc * lo;
             *(f32x4*)(cp + 4) = r1v[s] + sc * hi;
           } else {
-            *(f32x4*)cp = r0v[s] + lo;
-            *(f32x4*)(cp + 4) = r1v[s] + hi;
+            const f32x4 o0 = r0v[s] + lo, o1 = r1v[s] + hi;
+            *(f32x4*)cp = o0;
+            *(f32x4*)(cp + 4) = o1;
+            if (g.xb) {                  // LayerNorm folded into the next GEMM (DkdGemm.xb): bf16 copy of the new x + this tile's row sums
+              *(uint4*)&((bf16_t*)g.xb)[(size_t)m * g.ldxb + n] = uint4{pack2bf(o0[0], o0[1]), pack2bf(o0[2], o0[3]), pack2bf(o1[0], o1[1]),
+                                                                         pack2bf(o1[2], o1[3])};
+              float s1 = (o0[0] + o0[1]) + (o0[2] + o0[3]) + (o1[0] + o1[1]) + (o1[2] + o1[3]);
+              float s2 = (o0[0] * o0[0] + o0[1] * o0[1]) + (o0[2] * o0[2] + o0[3] * o0[3]) + (o1[0] * o1[0] + o1[1] * o1[1]) +
+                         (o1[2] * o1[2] + o1[3] * o1[3]);
+#pragma unroll
+              for (int o = 1; o < TPR; o <<= 1) {       // the TPR lanes of this row (TPR = 16 or 8: inside one wave)
+                s1 += __shfl_xor(s1, o, 64);
+                s2 += __shfl_xor(s2, o, 64);
+              }
+              if (tid % TPR == 0) {
+                atomicAdd(&g.rowstats[2 * (size_t)m], s1);
+                atomicAdd(&g.rowstats[2 * (size_t)m + 1], s2);
+              }
+            }
           }
         }
       }
@@ -471,7 +488,9 @@ constexpr uint32_t vmcnt_imm(int n) { return (uint32_t)((n & 15) | ((n >> 4) << 
 // FAST: 0 = the generic fused epilogue (runtime flags, row maps); 1 = C(bf16) = acc + bias; 2 = C(bf16) = gelu(acc + bias);
 // 3 = C(f32) = resid + acc + bias (+ bf16 tap); all with identity row maps -- the two epilogues the teacher's qkv / fc1 use, compiled without the per-vector flag tests, row-map
 // divisions and spilled-SGPR reads of the generic path (they, not the GELU arithmetic, were most of the epilogue's VALU time).
-template <int ABL, int EOPS, int WN, int FAST>
+// FOLD (FAST 1 / 2 only): the LayerNorm in front of this Linear is folded into it (DkdGemm.ln_stats / ln_c): the epilogue is
+// C = rstd[m] (acc - mean[m] c[n]) + bias[n] with the row statistics from the producer GEMM's row sums.
+template <int ABL, int EOPS, int WN, int FAST, bool FOLD = false>
 __global__ __launch_bounds__(128 * WN, WN == 4 ? 1 : 2) void gemm_nt256_kernel(const DkdGemm g, const int n_tiles_cg) {
   constexpr int BN = 64 * WN, NW = 2 * WN;          // tile columns, waves
   constexpr int WHALF = 16384, UNIT = WHALF + BN * 64, RING = WN == 4 ? 5 : 3;
@@ -669,6 +688,24 @@ __global__ __launch_bounds__(128 * WN, WN == 4 ? 1 : 2) void gemm_nt256_kernel(c
           bias8[jp] = f32x8{b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
         }
       }
+      f32x8 c8[2];                       // FOLD: row sums of the gamma-scaled weight for this lane's columns; mean / rstd of its 8 rows
+      float mu8[8], rs8[8];
+      if (FOLD) {
+        const float invK = 1.f / (float)g.K;
+#pragma unroll
+        for (int jp = 0; jp < 2; ++jp) {
+          const f32x4 c0 = *(const f32x4*)&g.ln_c[nb + jp * 32], c1 = *(const f32x4*)&g.ln_c[nb + jp * 32 + 4];
+          c8[jp] = f32x8{c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          int m = m0 + wr * 128 + i * 16 + frow;
+          m = m < g.M ? m : g.M - 1;
+          const float2 st = *(const float2*)&g.ln_stats[2 * (size_t)m];
+          mu8[i] = st.x * invK;
+          rs8[i] = rsqrtf(st.y * invK - mu8[i] * mu8[i] + g.ln_eps);
+        }
+      }
       constexpr bool FAST3 = FAST == 3;
       if (FAST3) {
         // C(f32) = resid + acc + bias, identity row maps, optional bf16 tap: 32 contiguous bytes per lane, 128 per row and block.
@@ -679,6 +716,7 @@ __global__ __launch_bounds__(128 * WN, WN == 4 ? 1 : 2) void gemm_nt256_kernel(c
 #pragma unroll
         for (int i0 = 0; i0 < 8; i0 += GB) {
           f32x4 rr[GB][4];
+          float st1[GB] = {0.f, 0.f}, st2[GB] = {0.f, 0.f};
 #pragma unroll
           for (int gi = 0; gi < GB; ++gi) {
             const int m = m0 + wr * 128 + (i0 + gi) * 16 + frow;
@@ -701,10 +739,35 @@ __global__ __launch_bounds__(128 * WN, WN == 4 ? 1 : 2) void gemm_nt256_kernel(c
                 *(uint4*)(tp + 32) = pack8(v1);
               }
               float* cp = (float*)g.C + (size_t)m * g.ldc + nb;
-              *(f32x4*)cp = rr[gi][0] + f32x4{v0[0], v0[1], v0[2], v0[3]};
-              *(f32x4*)(cp + 4) = rr[gi][1] + f32x4{v0[4], v0[5], v0[6], v0[7]};
-              *(f32x4*)(cp + 32) = rr[gi][2] + f32x4{v1[0], v1[1], v1[2], v1[3]};
-              *(f32x4*)(cp + 36) = rr[gi][3] + f32x4{v1[4], v1[5], v1[6], v1[7]};
+              const f32x4 o0 = rr[gi][0] + f32x4{v0[0], v0[1], v0[2], v0[3]}, o1 = rr[gi][1] + f32x4{v0[4], v0[5], v0[6], v0[7]};
+              const f32x4 o2 = rr[gi][2] + f32x4{v1[0], v1[1], v1[2], v1[3]}, o3 = rr[gi][3] + f32x4{v1[4], v1[5], v1[6], v1[7]};
+              *(f32x4*)cp = o0;
+              *(f32x4*)(cp + 4) = o1;
+              *(f32x4*)(cp + 32) = o2;
+              *(f32x4*)(cp + 36) = o3;
+              if (g.xb) {                // LayerNorm folded into the next GEMM: bf16 copy of the new x + row sums of these 16 columns
+                bf16_t* xp = &((bf16_t*)g.xb)[(size_t)m * g.ldxb + nb];
+                *(uint4*)xp = uint4{pack2bf(o0[0], o0[1]), pack2bf(o0[2], o0[3]), pack2bf(o1[0], o1[1]), pack2bf(o1[2], o1[3])};
+                *(uint4*)(xp + 32) = uint4{pack2bf(o2[0], o2[1]), pack2bf(o2[2], o2[3]), pack2bf(o3[0], o3[1]), pack2bf(o3[2], o3[3])};
+                const f32x4 sq = o0 * o0 + o1 * o1 + o2 * o2 + o3 * o3, sm = o0 + o1 + o2 + o3;
+                st1[gi] = (sm[0] + sm[1]) + (sm[2] + sm[3]);
+                st2[gi] = (sq[0] + sq[1]) + (sq[2] + sq[3]);
+              }
+            }
+          }
+          if (g.xb) {                    // (wave-uniform) the four lanes fg of a row hold its 64 columns of this wave: combine, one adds
+#pragma unroll
+            for (int gi = 0; gi < GB; ++gi) {
+              float a1 = st1[gi], a2 = st2[gi];
+              a1 += __shfl_xor(a1, 16, 64);
+              a2 += __shfl_xor(a2, 16, 64);
+              a1 += __shfl_xor(a1, 32, 64);
+              a2 += __shfl_xor(a2, 32, 64);
+              const int m = m0 + wr * 128 + (i0 + gi) * 16 + frow;
+              if (fg == 0 && m < g.M) {
+                atomicAdd(&g.rowstats[2 * (size_t)m], a1);
+                atomicAdd(&g.rowstats[2 * (size_t)m + 1], a2);
+              }
             }
           }
         }
@@ -721,7 +784,9 @@ __global__ __launch_bounds__(128 * WN, WN == 4 ? 1 : 2) void gemm_nt256_kernel(c
 #pragma unroll
           for (int jp = 0; jp < 2; ++jp) {
             const f32x4 lo = acc[i][2 * jp], hi = acc[i][2 * jp + 1];
-            f32x8 v = f32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]} + bias8[jp];
+            f32x8 v = f32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            if (FOLD) v = rs8[i] * (v - mu8[i] * c8[jp]) + bias8[jp];
+            else v += bias8[jp];
             if (FAST == 2) {
 #pragma unroll
               for (int e = 0; e < 8; e += 2) {
@@ -1599,6 +1664,10 @@ extern "C" int dkd_gemm_nt(const DkdGemm* gp, void* stream) {
   DKD_CHECK_ARG(!(g.epi & DKD_EPI_ACCUM) || (g.epi & DKD_EPI_OUT_F32), "gemm_nt: ACCUM needs f32 output");
   DKD_CHECK_ARG(!g.rowscale || g.rows_per_sample > 0, "gemm_nt: rowscale needs rows_per_sample");
   DKD_CHECK_ARG(!(g.epi & DKD_EPI_RELU_GATE) || g.preact, "gemm_nt: RELU_GATE without the gate (preact) pointer");
+  DKD_CHECK_ARG((g.xb != nullptr) == (g.rowstats != nullptr), "gemm_nt: xb and rowstats come together (LayerNorm fold, producer side)");
+  DKD_CHECK_ARG((g.ln_stats != nullptr) == (g.ln_c != nullptr), "gemm_nt: ln_stats and ln_c come together (LayerNorm fold, consumer side)");
+  DKD_CHECK_ARG(!g.xb || (g.ldxb % 8 == 0 && ((uintptr_t)g.xb & 15) == 0 && ((uintptr_t)g.rowstats & 7) == 0), "gemm_nt: xb rows must be 16-byte aligned");
+  DKD_CHECK_ARG(!(g.conv_hw > 0 && (g.xb || g.ln_stats)), "gemm_nt: no LayerNorm fold on the convolution path");
   if (g.conv_hw > 0) {
     DKD_CHECK_ARG(g.K % 9 == 0 && (g.K / 9) % 64 == 0 && g.lda >= g.K / 9 && g.amap.rpg == 0 && g.M % (g.conv_hw * g.conv_hw) == 0,
                   "gemm_nt(conv3x3): need K = 9 * Cin, Cin %% 64 == 0, identity A row map, M a multiple of hw^2 (K=%d M=%d hw=%d)", g.K, g.M,
@@ -1654,6 +1723,10 @@ extern "C" int dkd_gemm_nt(const DkdGemm* gp, void* stream) {
       g2.C = (char*)g.C + (size_t)M1 * g.ldc * 4;
       g2.resid = g.resid + (size_t)M1 * g.ldr;
       if (g.tap) g2.tap = (char*)g.tap + (size_t)M1 * g.ldt * 2;
+      if (g.xb) {
+        g2.xb = (char*)g.xb + (size_t)M1 * g.ldxb * 2;
+        g2.rowstats = g.rowstats + 2 * (size_t)M1;
+      }
       DkdGemm g1 = g;
       g1.M = M1;
       {
@@ -1663,6 +1736,17 @@ extern "C" int dkd_gemm_nt(const DkdGemm* gp, void* stream) {
       }
       return dkd_gemm_nt(&g2, stream);
     }
+  }
+  // LayerNorm fold: only the kernels that serve the wide teacher GEMMs implement it (the caller checks with the same shape rules:
+  // deltakd_amd.vit.ln_fold_supported)
+  if (g.ln_stats && !(wide && !(g.epi & (DKD_EPI_RESID | DKD_EPI_DGELU | DKD_EPI_OUT_F32)) && !g.tap && !g.preact && g.cmap.rpg == 0 && g.amap.rpg == 0 &&
+                      !g.rowscale && (g.epi == DKD_EPI_BIAS || g.epi == (DKD_EPI_BIAS | DKD_EPI_GELU)))) {
+    dkd_set_error("gemm_nt: LayerNorm fold (consumer) needs the wide-kernel path: N %% 256 == 0, >= 1024 tiles, K >= 512, bias (+ GELU) epilogue, bf16 output");
+    return DKD_ERR_UNSUPPORTED;
+  }
+  if (g.xb && !((wide && fast3w) || (!wide && !narrow && fast3w && g.N % 128 == 0))) {
+    dkd_set_error("gemm_nt: LayerNorm fold (producer) needs the f32 residual epilogue with identity row maps and N %% 128 == 0");
+    return DKD_ERR_UNSUPPORTED;
   }
   DkdProbeScope probe(wide ? 2 : (narrow ? 1 : 0), 2.0 * g.M * g.N * g.K, 0.0, as_stream(stream));
   if (wide) {
@@ -1680,7 +1764,12 @@ extern "C" int dkd_gemm_nt(const DkdGemm* gp, void* stream) {
     const bool plain16 = !(g.epi & (DKD_EPI_RESID | DKD_EPI_DGELU | DKD_EPI_OUT_F32)) && !g.tap && !g.preact;
     const bool ident = g.cmap.rpg == 0 && !g.rowscale && (g.epi & DKD_EPI_BIAS);
     const int fast = !(plain16 && ident) ? 0 : (g.epi == DKD_EPI_BIAS ? 1 : (g.epi == (DKD_EPI_BIAS | DKD_EPI_GELU) ? 2 : 0));
-    if (fast == 1) hipLaunchKernelGGL((gemm_nt256_kernel<DKD_NT256_ABL, 16, 4, 1>), grid, dim3(512), 0, as_stream(stream), g, n_tiles);
+    if (fast == 1 && g.ln_stats) hipLaunchKernelGGL((gemm_nt256_kernel<DKD_NT256_ABL, 16, 4, 1, true>), grid, dim3(512), 0, as_stream(stream), g, n_tiles);
+    else if (fast == 2 && g.ln_stats) hipLaunchKernelGGL((gemm_nt256_kernel<DKD_NT256_ABL, 16, 4, 2, true>), grid, dim3(512), 0, as_stream(stream), g, n_tiles);
+    else if (g.ln_stats) {
+      dkd_set_error("gemm_nt: LayerNorm fold (consumer): unsupported epilogue");
+      return DKD_ERR_UNSUPPORTED;
+    } else if (fast == 1) hipLaunchKernelGGL((gemm_nt256_kernel<DKD_NT256_ABL, 16, 4, 1>), grid, dim3(512), 0, as_stream(stream), g, n_tiles);
     else if (fast == 2) hipLaunchKernelGGL((gemm_nt256_kernel<DKD_NT256_ABL, 16, 4, 2>), grid, dim3(512), 0, as_stream(stream), g, n_tiles);
     else if (plain16) hipLaunchKernelGGL((gemm_nt256_kernel<DKD_NT256_ABL, 16, 4, 0>), grid, dim3(512), 0, as_stream(stream), g, n_tiles);
     // f32 residual epilogue on the wide path: N = 768 (teacher proj / fc2) when >= 3 batches go through the teacher in one call

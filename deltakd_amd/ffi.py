@@ -45,6 +45,7 @@ class Gemm(C.Structure):
         ("rowscale", C.c_void_p), ("rows_per_sample", C.c_int32),
         ("preact", C.c_void_p), ("ldp", C.c_int32),
         ("tap", C.c_void_p), ("ldt", C.c_int32), ("conv_hw", C.c_int32),
+        ("xb", C.c_void_p), ("ldxb", C.c_int32), ("rowstats", C.c_void_p), ("ln_stats", C.c_void_p), ("ln_c", C.c_void_p), ("ln_eps", C.c_float),
     ]
 
 
@@ -54,7 +55,8 @@ class Block(C.Structure):
                 [(n, C.c_void_p) for n in ("ln1_w", "ln1_b", "ln2_w", "ln2_b", "qkv_b", "proj_b", "fc1_b", "fc2_b",
                                            "qkv_w", "proj_w", "fc1_w", "fc2_w", "qkv_wt", "proj_wt", "fc1_wt", "fc2_wt",
                                            "s1", "s2", "x", "x1", "x2", "y1", "qkv", "o", "y2", "pre", "h", "tap",
-                                           "mean1", "rstd1", "mean2", "rstd2", "lse")] + [("fuse_mlp", C.c_int32)])
+                                           "mean1", "rstd1", "mean2", "rstd2", "lse")] + [("fuse_mlp", C.c_int32), ("ln_fold", C.c_int32)] +
+                [(n, C.c_void_p) for n in ("qkv_c", "fc1_c", "stats1", "stats2", "stats_next", "xb")])
 
 
 class BlockGrads(C.Structure):

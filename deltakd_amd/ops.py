@@ -24,7 +24,7 @@ def _is_f32(t):
 
 def gemm_nt(a, b, out=None, *, M=None, bias=None, gelu=False, dgelu=False, relu=False, preact=None, resid=None, rowscale=None,
             rows_per_sample=0, tap=None, out_f32=False, accumulate=False, amap=IDENT, cmap=IDENT, rmap=IDENT, out_rows=None,
-            K=None, N=None, conv_hw=0, relu_gate=None):
+            K=None, N=None, conv_hw=0, relu_gate=None, xb=None, rowstats=None, ln_stats=None, ln_c=None, ln_eps=1e-6):
     """out[M, N] = epilogue(a[M, K] @ b[N, K]^T); a, b bf16 (2-D, row stride = stride(0)).
 
     ``M`` = logical rows (defaults to a.shape[0]; with ``amap`` the rows are gathered through the map).
@@ -32,6 +32,8 @@ def gemm_nt(a, b, out=None, *, M=None, bias=None, gelu=False, dgelu=False, relu=
     ``conv_hw`` > 0: a is the activation [B * hw * hw, Cin] of a 3 x 3 / pad 1 convolution on the hw x hw token grid, b its weight as
     [N, (ky, kx, cin)] (K = 9 Cin): implicit GEMM, the neighbourhood is gathered by the kernel (include/dkd.h, DkdGemm.conv_hw).
     ``relu_gate`` (bf16 [M, N]): out = gate > 0 ? out : 0 -- the backward of a ReLU given its output.
+    LayerNorm fold (include/dkd.h, DkdGemm.xb): ``xb`` (bf16 [M, N]) + ``rowstats`` (f32 [M, 2], zeroed by the caller) on the f32-residual
+    GEMM that produces x; ``ln_stats`` (those sums) + ``ln_c`` (f32 [N] row sums of b = bf16(gamma * W)) on the Linear behind the norm.
     """
     if conv_hw:
         K = 9 * a.shape[1]
@@ -83,6 +85,12 @@ def gemm_nt(a, b, out=None, *, M=None, bias=None, gelu=False, dgelu=False, relu=
         epi |= EPI_OUT_F32
     if accumulate:
         epi |= EPI_ACCUM
+    if xb is not None:
+        assert xb.dtype == BF16 and rowstats.dtype == F32 and rowstats.is_contiguous()
+        g.xb, g.ldxb, g.rowstats = ptr(xb), xb.stride(0), ptr(rowstats)
+    if ln_stats is not None:
+        assert ln_stats.dtype == F32 and ln_c.dtype == F32 and ln_stats.is_contiguous()
+        g.ln_stats, g.ln_c, g.ln_eps = ptr(ln_stats), ptr(ln_c), ln_eps
     g.epi = epi
     check(lib().dkd_gemm_nt(C.byref(g), stream()), "gemm_nt")
     return out

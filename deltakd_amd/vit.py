@@ -424,15 +424,48 @@ def _block_backward(g, gtap, model, blk: Block, saved):
     return g
 
 
+def ln_fold_supported(M, D, hidden):
+    """Shapes for which a block's LayerNorms can be folded into the GEMMs around them (include/dkd.h, DkdGemm.xb): the consumers (qkv,
+    fc1) must take libdkd's wide kernel -- N % 256 == 0 and >= 1024 tiles of 256 x 256, K = D >= 512 -- and the producers (proj, fc2) its
+    f32-residual epilogues (N = D % 128 == 0).  True for the DeiT-base / ViT-L teachers at the training batch; DKD_NO_LN_FOLD=1 keeps
+    the separate LayerNorm launches (A/B)."""
+    if os.environ.get("DKD_NO_LN_FOLD") or D < 512 or D % 128 or D % 64:
+        return False
+    panels = (M + 255) // 256
+    for n in (3 * D, hidden):
+        if n % 256 or panels * (n // 256) < 1024 or M * D >= 2 ** 31 or n * D >= 2 ** 31:
+            return False
+    return True
+
+
+def _folded_linear(model, norm, lin):
+    """(bf16(gamma * W), W beta + b, row sums of the bf16 matrix) of a LayerNorm -> Linear pair, cached until a parameter changes."""
+    cache = _rt(model).setdefault("ln_fold_w", {})
+    key = (id(norm), id(lin))
+    stamp = tuple((p._version, p.data_ptr()) for p in (norm.weight, norm.bias, lin.weight, lin.bias)) + (model._shadow.generation,)
+    hit = cache.get(key)
+    if hit is not None and hit[0] == stamp:
+        return hit[1]
+    with torch.no_grad():
+        w = lin.weight.detach().float()
+        wf = (w * norm.weight.detach().float()[None, :]).to(BF16).contiguous()
+        bias = (w @ norm.bias.detach().float() + lin.bias.detach().float()).contiguous()
+        csum = wf.float().sum(1).contiguous()
+    cache[key] = (stamp, (wf, bias, csum))
+    return wf, bias, csum
+
+
 def _blocks_forward_infer(x, B, N, model, scales, want):
     """Inference pass over all blocks in ONE library call: in-place fp32 residual stream, activation buffers shared by all
-    blocks, taps only for the blocks in ``want``.  Returns (x, taps list)."""
+    blocks, taps only for the blocks in ``want``.  Returns (x, taps list).  Where the shapes allow it (``ln_fold_supported``: the
+    DeiT-base / ViT-L teachers at the training batch) the LayerNorms are folded into the GEMMs around them -- no LayerNorm launches
+    except the first block's norm1."""
     blocks = model.blocks
     depth = len(blocks)
     M, D = x.shape
     Hd = blocks[0].mlp.fc1.out_features
     dev = x.device
-    sizes = [M * D, M * 3 * D, M * D, M * Hd]            # y (LN1 and LN2 outputs alias), qkv, o, h
+    sizes = [M * D, M * 3 * D, M * D, M * Hd]            # y (LN1 and LN2 outputs alias; with the fold: the bf16 copy of x), qkv, o, h
     off, tot = [], 0
     for n in sizes:
         off.append(tot)
@@ -441,6 +474,11 @@ def _blocks_forward_infer(x, B, N, model, scales, want):
     p = slab.data_ptr()
     arr = (ffi.Block * depth)()
     taps = [None] * depth
+    fold = ln_fold_supported(M, D, Hd) and all(s is None for s in scales)
+    keep = []                                             # folded weights / statistics referenced by the descriptors
+    if fold:
+        stats = torch.zeros(2 * depth, M, 2, device=dev, dtype=F32)
+        keep.append(stats)
     for i, blk in enumerate(blocks):
         bs = arr[i]
         _fill_weights(bs, blk, model._shadow, B, N, backward=False)
@@ -451,6 +489,19 @@ def _blocks_forward_infer(x, B, N, model, scales, want):
         if i in want:
             taps[i] = torch.empty(M, D, device=dev, dtype=BF16)
             bs.tap = taps[i].data_ptr()
+        if fold:
+            bits = 2 | (1 if i > 0 else 0) | (4 if i + 1 < depth else 0)
+            bs.ln_fold, bs.xb = bits, p + off[0]
+            bs.stats1, bs.stats2 = stats[2 * i].data_ptr(), stats[2 * i + 1].data_ptr()
+            if i + 1 < depth:
+                bs.stats_next = stats[2 * i + 2].data_ptr()
+            if i > 0:
+                wf, bias, csum = _folded_linear(model, blk.norm1, blk.attn.qkv)
+                bs.qkv_w, bs.qkv_b, bs.qkv_c = wf.data_ptr(), bias.data_ptr(), csum.data_ptr()
+                keep.append((wf, bias, csum))
+            wf, bias, csum = _folded_linear(model, blk.norm2, blk.mlp.fc1)
+            bs.fc1_w, bs.fc1_b, bs.fc1_c = wf.data_ptr(), bias.data_ptr(), csum.data_ptr()
+            keep.append((wf, bias, csum))
     ffi.check(ffi.lib().dkd_blocks_fwd(arr, depth, ffi.stream()), "blocks_fwd")
     return x, taps
 

@@ -76,6 +76,22 @@ typedef struct {
                          K = 9 * Cin, B the weight as [N, (ky, kx, cin)]; the 3 x 3 neighbourhood is gathered by the kernel's
                          source addressing (zero padding included), no [M, 9 Cin] matrix exists.  The input gradient is the same
                          call on dY with the weight flipped and transposed ([Cin, (2 - ky, 2 - kx, cout)]).  Cin % 64 == 0. */
+  /* LayerNorm folded into the GEMMs around it ([3P] timm Block: x -> norm -> Linear).  For a frozen (inference) model the separate
+   * LayerNorm pass -- a pure streaming kernel at the HBM rate -- disappears:
+   *   producer (the residual GEMM that writes x: proj / fc2, epilogue BIAS | RESID | OUT_F32 with identity row maps): also stores
+   *     xb = bf16(x) (row stride ldxb) and adds every row's  sum x, sum x^2  over this GEMM's N columns into rowstats f32 [M][2]
+   *     (atomically: the caller zeroes it; a row's N columns may come from several tiles / launches);
+   *   consumer (the Linear behind the norm, epilogue BIAS or BIAS | GELU, bf16 output): A = xb, B = bf16(gamma * W), bias = W beta + b,
+   *     ln_c f32 [N] = row sums of that B, ln_stats = the producer's rowstats (over exactly K columns):
+   *         C[m, n] = rstd[m] (acc[m, n] - mean[m] ln_c[n]) + bias[n],   mean = s1 / K, rstd = rsqrt(s2 / K - mean^2 + ln_eps)
+   * which equals Linear(LayerNorm(x)) with x rounded to bf16 BEFORE it is centred instead of after (same error against fp32:
+   * tools_dev/ln_fold_probe.py, tests/test_fullsize_gpu.py).  Taken by the kernels that serve the wide teacher GEMMs; others refuse. */
+  void* xb;
+  int32_t ldxb;
+  float* rowstats;
+  const float* ln_stats;
+  const float* ln_c;
+  float ln_eps;
 } DkdGemm;
 
 /* C[M,N] = epilogue(A[M,K] * B[N,K]^T).  Replaces nn.Linear / Conv2d-as-GEMM forward and the dgrad GEMMs
@@ -277,6 +293,14 @@ typedef struct {
                                         the forward; y2 / pre / h and the backward's dF / dH sized for M rounded up to 16 rows -- the workspace
                                         queries below already are; `pre` is then in that kernel pair's private order).  The caller sets it once:
                                         the same descriptor goes to the forward and to the backward.                       */
+  int32_t ln_fold;                   /* inference only (pre == NULL); bits: 1 = norm1 is folded into the qkv GEMM (qkv_w = bf16(ln1_w * W), qkv_b =
+                                        W ln1_b + b, qkv_c = row sums of that qkv_w; the block input's bf16 copy is in `xb`, its row sums in stats1
+                                        -- left there by the previous block); 2 = norm2 likewise (fc1_w, fc1_b, fc1_c; proj writes xb / stats2);
+                                        4 = fc2 writes xb and stats_next for the next block's bit 1.  See DkdGemm.xb.  The shapes must take the
+                                        wide-kernel path (dkd_gemm_nt refuses otherwise); stats buffers f32 [M][2], zeroed by the caller.   */
+  const float *qkv_c, *fc1_c;
+  float *stats1, *stats2, *stats_next;
+  void* xb;                          /* bf16 [M, D]                                                                        */
 } DkdBlock;
 
 typedef struct {

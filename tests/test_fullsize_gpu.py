@@ -404,6 +404,76 @@ def test_wide_gemm_column_groups(ops):
     assert rel(cols, ref_cols) < 2e-2
 
 
+@pytest.mark.parametrize("M,N,K", [(B * NT, 768, 3072), (B * NT, 768, 768), (1000, 256, 128)])
+def test_layernorm_fold_producer(ops, M, N, K):
+    """The f32-residual GEMM that also leaves bf16(x) and the rows' sum x, sum x^2 for the LayerNorm folded into the next GEMM
+    (DkdGemm.xb / rowstats): the wide kernel's whole rounds + the 128-row kernel's tail (fc2's split), the 128-row kernel alone (proj),
+    a small problem.  A row's N columns come from several tiles (and two launches): the sums are accumulated atomically."""
+    a = rnd(M, K, seed=41).to(BF16)
+    w = rnd(N, K, scale=0.05, seed=42).to(BF16)
+    bias = rnd(N, seed=43)
+    x0 = rnd(M, N, seed=44, scale=3.0) + 0.5
+    x = x0.clone()
+    xb = torch.empty(M, N, device=DEV, dtype=BF16)
+    stats = torch.zeros(M, 2, device=DEV)
+    tap = torch.empty(M, N, device=DEV, dtype=BF16)
+    ops.gemm_nt(a, w, out=x, bias=bias, resid=x, tap=tap, xb=xb, rowstats=stats)
+    torch.cuda.synchronize()
+    for lo in (0, M // 2 - 100, M - 300):
+        hi = min(M, lo + 300)
+        ref = x0[lo:hi] + a[lo:hi].float() @ w.float().t() + bias
+        assert rel(x[lo:hi], ref) < 1e-4, lo
+    assert torch.equal(xb, x.to(BF16)), "xb must be the bf16 rounding of the x this launch wrote"
+    assert rel(stats[:, 0], x.sum(1)) < 1e-5 and rel(stats[:, 1], (x * x).sum(1)) < 1e-5
+    assert rel(tap[:300], a[:300].float() @ w.float().t() + bias) < 1e-2
+
+
+@pytest.mark.parametrize("gelu", [False, True])
+def test_layernorm_fold_consumer(ops, gelu):
+    """The Linear behind a folded LayerNorm on the wide kernel: C = rstd (xb W'^T - mean c) + b' from the producer's row sums equals
+    Linear(LayerNorm(x)) computed in fp32 -- to the same tolerance as the unfolded bf16 path (LN output rounded to bf16, then GEMM)."""
+    M, N, K = 16384 + 37, 4096, 768
+    x = rnd(M, K, seed=51, scale=2.0) + 0.3
+    gamma, beta = 1.0 + 0.2 * rnd(K, seed=52), 0.1 * rnd(K, seed=53)
+    w = rnd(N, K, scale=0.04, seed=54)
+    bias = rnd(N, seed=55)
+    ref = torch.nn.functional.layer_norm(x, (K,), gamma, beta, 1e-6) @ w.t() + bias
+    if gelu:
+        ref = torch.nn.functional.gelu(ref)
+    wf = (w * gamma[None, :]).to(BF16).contiguous()
+    stats = torch.stack([x.sum(1), (x * x).sum(1)], 1).contiguous()
+    got = ops.gemm_nt(x.to(BF16), wf, bias=(w @ beta + bias).contiguous(), gelu=gelu, ln_stats=stats, ln_c=wf.float().sum(1).contiguous())
+    y, _, _ = ops.layernorm_fwd(x, gamma, beta)
+    unfolded = ops.gemm_nt(y, w.to(BF16), bias=bias, gelu=gelu)
+    torch.cuda.synchronize()
+    e_fold, e_std = rel(got, ref), rel(unfolded, ref)
+    print(f"folded vs fp32 {e_fold:.3e}; unfolded bf16 path vs fp32 {e_std:.3e}")
+    assert e_fold < 1e-2 and e_fold < 2.0 * e_std + 1e-3
+    # shapes the fold does not serve are refused, not silently computed without it
+    with pytest.raises(RuntimeError, match="LayerNorm fold"):
+        ops.gemm_nt(x[:512].to(BF16), wf, bias=bias, ln_stats=stats[:512].contiguous(), ln_c=bias)
+
+
+def test_teacher_forward_with_folded_layernorms(models, monkeypatch):
+    """The whole deit_base_distilled teacher at the training batch with its LayerNorms folded into the GEMMs (24 of 25 LayerNorm launches
+    gone) against the same forward with the separate LayerNorm kernels (DKD_NO_LN_FOLD=1): logits and the taps of blocks 0, 1, 11.  Both
+    are bf16-operand pipelines that round at different places, each ~0.7 % from fp32 in relative L2 (tools_dev/ln_fold_probe.py): 2e-2 of the largest element between them;
+    the per-sample independence test above compares the folded batch-256 path with the unfolded small-batch path as well."""
+    from deltakd_amd import vit
+    t = models
+    assert vit.ln_fold_supported(B * NT, 768, 3072) and not vit.ln_fold_supported(24 * NT, 768, 3072)
+    x = rnd(B, 3, 224, 224, seed=61)
+    with torch.no_grad():
+        z_f, taps_f = t.forward_with_taps(x, (0, 1, 11))
+        monkeypatch.setenv("DKD_NO_LN_FOLD", "1")
+        z_u, taps_u = t.forward_with_taps(x, (0, 1, 11))
+    torch.cuda.synchronize()
+    assert rel(z_f, z_u) < 2e-2, rel(z_f, z_u)
+    for i in (0, 1, 11):
+        assert rel(taps_f[i], taps_u[i]) < 2e-2, (i, rel(taps_f[i], taps_u[i]))
+    assert not torch.equal(taps_f[11], taps_u[11]), "the two runs were meant to take different kernels"
+
+
 REAL = {  # kind -> (student, teacher, batch): BASELINE.json configs 2, 4, 3 and 5
     "soft": ("deit_tiny_distilled_patch16_224", "deit_small_distilled_patch16_224", 4),
     "lrkd": ("deit_tiny_patch16_224", "deit_base_distilled_patch16_224", 4),

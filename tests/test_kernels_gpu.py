@@ -707,3 +707,49 @@ def test_ema_on_flat_storage():
     for k, v in ema.ema.state_dict().items():
         want = 0.9 * before[k] + 0.1 * m.state_dict()[k]
         close(v, want, 1e-6, k)
+
+
+@pytest.mark.parametrize("Dt,B", [(768, 5), (128, 3), (384, 2)])
+def test_saliency_scores(ops, Dt, B):
+    """dkd_saliency_scores + the fp32-accurate projections (deltakd_amd.models._project_f32) against the reference's scorer arithmetic in
+    torch fp32 (model/models.py:14-56, model/misc.py:38-165): the three methods, teacher tokens [CLS, DIST, 196 patches], 8 heads
+    (head_dim 96 at Dt = 768).  The scores are ~1 / 197: 1e-4 relative to their maximum resolves a ranking far below the tap noise."""
+    from types import SimpleNamespace
+    from deltakd_amd.misc import saliency_scores
+    from deltakd_amd.models import SimpleAttention, SimpleCrossAttention
+    N, H = 198, 8
+    t = rnd(B, N, Dt, seed=900, scale=1.5).to(BF16)
+    tf = t.float()
+    torch.manual_seed(7)
+    sa, ca = SimpleAttention(Dt, H).to(dev()), SimpleCrossAttention(Dt, H).to(dev())
+    with torch.no_grad():                          # default-initialised projections give nearly uniform attention: sharpen it
+        for lin in (sa.qk, ca.q, ca.k):
+            lin.weight.mul_(6.0)
+    hd, scale = Dt // H, (Dt // H) ** -0.5
+
+    def heads(x):
+        return x.reshape(x.shape[0], x.shape[1], H, hd).permute(0, 2, 1, 3)
+    with torch.no_grad():
+        # method 1
+        qk = tf[:, 2:] @ sa.qk.weight.t() + sa.qk.bias
+        a = ((heads(qk[..., :Dt]) @ heads(qk[..., Dt:]).transpose(-2, -1)) * scale).softmax(-1)
+        ref1 = a.mean(1).diagonal(dim1=-2, dim2=-1)
+        # method 2
+        cp = torch.cat([tf[:, :1], tf[:, 2:]], 1)
+        qk = cp @ sa.qk.weight.t() + sa.qk.bias
+        a = ((heads(qk[..., :Dt])[:, :, 0:1] @ heads(qk[..., Dt:]).transpose(-2, -1)) * scale).softmax(-1)
+        ref2 = a.mean(1).squeeze(1)[:, 1:]
+        # method 3
+        q = cp[:, :1] @ ca.q.weight.t() + ca.q.bias
+        k = cp[:, 1:] @ ca.k.weight.t() + ca.k.bias
+        ref3 = ((heads(q) @ heads(k).transpose(-2, -1)) * scale).softmax(-1).mean(1).squeeze(1)
+    for method, ref, mod in ((1, ref1, sa), (2, ref2, sa), (3, ref3, ca)):
+        got = saliency_scores(SimpleNamespace(saliency_attn=mod), t, method)
+        assert got.shape == ref.shape == (B, N - 2)
+        close(got, ref, 1e-4, f"method {method}")
+        assert ref.max() > 3 * ref.mean(), "the test's attention should not be uniform"
+    # the modules' own call contracts (what a caller of the reference's classes gets)
+    close(sa(tf[:, 2:]), ref1, 1e-4, "SimpleAttention.forward (float input: hi / lo split of x too)")
+    w = ca(cp[:, :1], cp[:, 1:])
+    assert w.shape == (B, 1, N - 2)
+    close(w[:, 0], ref3, 1e-4, "SimpleCrossAttention.forward")

@@ -309,14 +309,18 @@ __device__ __forceinline__ void nt_epilogue(const DkdGemm& g, const int vec_ok, 
                 s1 += __shfl_xor(s1, o, 64);
                 s2 += __shfl_xor(s2, o, 64);
               }
-              if (tid % TPR == 0) {
-                atomicAdd(&g.rowstats[2 * (size_t)m], s1);
-                atomicAdd(&g.rowstats[2 * (size_t)m + 1], s2);
-              }
+              // parked in LDS behind the tile staging: one lane per row adding its two sums (4 active lanes per wave instruction,
+              // 128 instructions per tile) cost proj +25 us; the tile's 256 sums go out below as 4 full-width atomic instructions
+              if (tid % TPR == 0) *(float2*)&cs[128 * BN + 2 * rl] = float2{s1, s2};
             }
           }
         }
       }
+    }
+    if (FAST == 3 && g.xb) {              // (uniform) rowstats[2 (m0 + r) + {0, 1}] += the row's sums over this tile's columns
+      __syncthreads();
+      const int m = m0 + (tid >> 1);
+      if (m < g.M) atomicAdd(&g.rowstats[2 * (size_t)m0 + tid], cs[128 * BN + tid]);
     }
     return;
   }
@@ -352,7 +356,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const DkdGemm g, const 
   constexpr int A_BYTES = BM * 128;       // 16 KiB
   constexpr int B_BYTES = BN * 128;
   constexpr int BUF = A_BYTES + B_BYTES;
-  constexpr int SMEM = (2 * BUF) > (128 * BN * 4) ? (2 * BUF) : (128 * BN * 4);
+  constexpr int SMEM = ((2 * BUF) > (128 * BN * 4) ? (2 * BUF) : (128 * BN * 4)) + (FAST == 3 ? 1024 : 0);   // + the tile's row sums (LN fold)
   __shared__ __attribute__((aligned(16))) char smem[SMEM];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -495,7 +499,7 @@ __global__ __launch_bounds__(128 * WN, WN == 4 ? 1 : 2) void gemm_nt256_kernel(c
   constexpr int BN = 64 * WN, NW = 2 * WN;          // tile columns, waves
   constexpr int WHALF = 16384, UNIT = WHALF + BN * 64, RING = WN == 4 ? 5 : 3;
   constexpr int AP = 8 / WN, PIECES = AP + 2;       // 1-KiB LDS-DMA pieces per wave per unit: A rows, then 2 of W rows
-  static_assert(EOPS == 0 || (EOPS == 16 && WN == 4), "the counted waits below encode 12 + 16 and 16 + 16");
+  static_assert(EOPS == 0 || ((EOPS == 16 || (FOLD && EOPS == 24)) && WN == 4), "the counted waits below encode (RING-2 | RING-1) * PIECES + EOPS < 64");
   __shared__ __attribute__((aligned(16))) char smem[RING * UNIT];   // WN = 4: all 160 KiB
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -641,6 +645,25 @@ __global__ __launch_bounds__(128 * WN, WN == 4 ? 1 : 2) void gemm_nt256_kernel(c
     __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): the next unit's fragments arrived under these MFMAs
   };
 
+  // FOLD: the row sums of a tile's 8 rows per lane (DkdGemm.ln_stats) are requested one tile AHEAD, right behind the previous tile's
+  // epilogue stores, through asm the compiler's vmcnt bookkeeping does not see: read in the epilogue itself, its wait for them was
+  // vmcnt(0) -- the LDS-DMA ring drained once per tile (+16 us per launch).  They count as 8 more known operations of that
+  // epilogue (EOPS = 24) and have long arrived when the next epilogue reads them (every phase waits for all but the newest units).
+  typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+  u32x2 stq[8];
+  auto request_stats = [&](const int kt) {
+    const int L = tile_of(kt < my_tiles ? kt : my_tiles - 1);
+    const int rm0 = (L / tiles_n) * 256;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      int m = rm0 + wr * 128 + i * 16 + frow;
+      m = m < g.M ? m : g.M - 1;
+      const float* sp = g.ln_stats + 2 * (size_t)m;
+      asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(stq[i]) : "v"(sp) : "memory");
+    }
+  };
+  if (FOLD) request_stats(0);
+
   for (int u = 0; u < RING; ++u) {
 #pragma unroll
     for (int c = 0; c < PIECES; ++c) piece(c, u);
@@ -699,11 +722,9 @@ __global__ __launch_bounds__(128 * WN, WN == 4 ? 1 : 2) void gemm_nt256_kernel(c
         }
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-          int m = m0 + wr * 128 + i * 16 + frow;
-          m = m < g.M ? m : g.M - 1;
-          const float2 st = *(const float2*)&g.ln_stats[2 * (size_t)m];
-          mu8[i] = st.x * invK;
-          rs8[i] = rsqrtf(st.y * invK - mu8[i] * mu8[i] + g.ln_eps);
+          asm volatile("" : "+v"(stq[i]));          // (requested a tile ago: see request_stats)
+          mu8[i] = __uint_as_float(stq[i].x) * invK;
+          rs8[i] = rsqrtf(__uint_as_float(stq[i].y) * invK - mu8[i] * mu8[i] + g.ln_eps);
         }
       }
       constexpr bool FAST3 = FAST == 3;
@@ -821,6 +842,7 @@ __global__ __launch_bounds__(128 * WN, WN == 4 ? 1 : 2) void gemm_nt256_kernel(c
     for (int i = 0; i < 8; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (FOLD) request_stats(k + 1);       // (behind this tile's stores, ahead of the refill pieces: part of the counted EOPS)
     // refill the slot the tile's last unit occupied (every wave passed that unit's barrier long ago... but not its READS: the
     // last phase's fragment reads were of the NEXT slot; this slot's reads completed before the last phase's barrier)
 #pragma unroll
@@ -1764,8 +1786,8 @@ extern "C" int dkd_gemm_nt(const DkdGemm* gp, void* stream) {
     const bool plain16 = !(g.epi & (DKD_EPI_RESID | DKD_EPI_DGELU | DKD_EPI_OUT_F32)) && !g.tap && !g.preact;
     const bool ident = g.cmap.rpg == 0 && !g.rowscale && (g.epi & DKD_EPI_BIAS);
     const int fast = !(plain16 && ident) ? 0 : (g.epi == DKD_EPI_BIAS ? 1 : (g.epi == (DKD_EPI_BIAS | DKD_EPI_GELU) ? 2 : 0));
-    if (fast == 1 && g.ln_stats) hipLaunchKernelGGL((gemm_nt256_kernel<DKD_NT256_ABL, 16, 4, 1, true>), grid, dim3(512), 0, as_stream(stream), g, n_tiles);
-    else if (fast == 2 && g.ln_stats) hipLaunchKernelGGL((gemm_nt256_kernel<DKD_NT256_ABL, 16, 4, 2, true>), grid, dim3(512), 0, as_stream(stream), g, n_tiles);
+    if (fast == 1 && g.ln_stats) hipLaunchKernelGGL((gemm_nt256_kernel<DKD_NT256_ABL, 24, 4, 1, true>), grid, dim3(512), 0, as_stream(stream), g, n_tiles);
+    else if (fast == 2 && g.ln_stats) hipLaunchKernelGGL((gemm_nt256_kernel<DKD_NT256_ABL, 24, 4, 2, true>), grid, dim3(512), 0, as_stream(stream), g, n_tiles);
     else if (g.ln_stats) {
       dkd_set_error("gemm_nt: LayerNorm fold (consumer): unsupported epilogue");
       return DKD_ERR_UNSUPPORTED;

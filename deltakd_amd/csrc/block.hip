@@ -26,7 +26,7 @@ int block_fwd(const DkdBlock& b, void* st) {
     g = mk(b.xb, b.qkv_w, b.qkv, M, 3 * D, D);
     g.ln_stats = b.stats1; g.ln_c = b.qkv_c; g.ln_eps = b.eps;
   } else {
-    TRY(dkd_layernorm_fwd(b.x, D, ID, b.ln1_w, b.ln1_b, b.y1, b.mean1, b.rstd1, M, D, b.eps, 0, st));
+    if (!b.ln1_ready) TRY(dkd_layernorm_fwd(b.x, D, ID, b.ln1_w, b.ln1_b, b.y1, b.mean1, b.rstd1, M, D, b.eps, 0, st));
     g = mk(b.y1, b.qkv_w, b.qkv, M, 3 * D, D);
   }
   g.epi = DKD_EPI_BIAS; g.bias = b.qkv_b;
@@ -42,7 +42,8 @@ int block_fwd(const DkdBlock& b, void* st) {
   if (b.fuse_mlp) {                       // LN2 + fc1 + GELU + fc2 + tap + DropPath + residual: one kernel, h stays in registers
     const bool save = b.pre != nullptr;
     return dkd_mlp192_fwd(b.x1, b.ln2_w, b.ln2_b, b.eps, b.fc1_w, b.fc1_b, b.fc2_wt, b.fc2_b, b.s2, b.N, b.x2, b.tap, save ? b.y2 : nullptr,
-                          b.pre, save ? b.h : nullptr, b.mean2, b.rstd2, M, Hd, st);
+                          b.pre, save ? b.h : nullptr, b.mean2, b.rstd2, b.next_ln1_w, b.next_ln1_b, b.next_y1, b.next_mean1, b.next_rstd1, M,
+                          Hd, st);
   }
   if (fold & 2) {
     g = mk(b.xb, b.fc1_w, b.h, M, Hd, D);

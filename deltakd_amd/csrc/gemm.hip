@@ -1906,7 +1906,8 @@ extern "C" int dkd_gemm_tn_group(const DkdTnProblem* probs, int32_t n, void* str
     // in a group the other problems supply the parallelism: 192 blocks per problem halve the atomically added partial tiles
     // (student-only step: 27.0k img/s at 384, 27.8k at 256, 29.1k at 192, 27.6k at 128)
     // ... and 96 each with four (29.6k / 29.5k / 30.5k / 29.0k img/s at 192 / 128 / 96 / 64)
-    if (tn192d_plan(q, &grp.p[grp.n], 1, n > 2 ? 96 : (n > 1 ? 192 : 384))) {
+    static const int blocks_env = getenv("DKD_TN_GROUP_BLOCKS") ? atoi(getenv("DKD_TN_GROUP_BLOCKS")) : 0;     // (dev: A/B of the split count)
+    if (tn192d_plan(q, &grp.p[grp.n], 1, blocks_env > 0 ? blocks_env : (n > 2 ? 96 : (n > 1 ? 192 : 384)))) {
       total += grp.p[grp.n].n_blocks;
       ++grp.n;
     } else {                            // shapes the ring kernel does not take: launched on their own

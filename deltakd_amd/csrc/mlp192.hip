@@ -95,6 +95,12 @@ struct Mlp192 {
   float* part;             // backward: per-workgroup partial sums [gridDim.x][2 * 192] (dgamma | dbeta)
   bf16_t* cast_out;        // backward: optional bf16 [M, 192] = rowscale_out[sample] * (updated g)
   const float* rowscale_out;
+  // forward, optional: the NEXT block's norm1 applied to the rows of x2 while they are complete in this kernel's epilogue
+  const float* nln_w;
+  const float* nln_b;
+  bf16_t* ny;              // bf16 [M, 192] = LN(x2)
+  float* nmean;
+  float* nrstd;
 };
 
 __device__ __forceinline__ bf16x8 as_bf16x8(const uint4 v) { return __builtin_bit_cast(bf16x8, v); }
@@ -519,9 +525,44 @@ __global__ __launch_bounds__(512, 2) void mlp192_kernel(const Mlp192 p) {
         for (int i = 0; i < 3; ++i) {
           const int c4 = 4 * (sl + 16 * i);
           const f32x4 f = *(const f32x4*)&cs[rl * F_CS + c4] + gam[i];
+          xv[i] += sc * f;                   // the new residual row
           if (live && (!(ABL & 128) || f[0] == 1234.5f)) {
             if (p.tap) *(uint2*)(p.tap + (size_t)row * F_D + c4) = uint2{pack2bf(f[0], f[1]), pack2bf(f[2], f[3])};
-            *(f32x4*)(p.x2 + (size_t)row * F_D + c4) = xv[i] + sc * f;
+            *(f32x4*)(p.x2 + (size_t)row * F_D + c4) = xv[i];
+          }
+        }
+        if (p.ny) {                          // (uniform) LayerNorm of the finished row for the next block: its norm1 launch disappears
+          float s = 0.f;
+#pragma unroll
+          for (int i = 0; i < 3; ++i) s += (xv[i][0] + xv[i][1]) + (xv[i][2] + xv[i][3]);
+#pragma unroll
+          for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+          const float mu = s / F_D;
+          float q = 0.f;
+#pragma unroll
+          for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float d = xv[i][e] - mu;
+              q += d * d;
+            }
+#pragma unroll
+          for (int o = 8; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+          const float rs = rsqrtf(q / F_D + p.eps);
+          if (live) {
+            if (sl == 0) {
+              p.nmean[row] = mu;
+              p.nrstd[row] = rs;
+            }
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+              const int c4 = 4 * (sl + 16 * i);
+              const f32x4 gw = *(const f32x4*)(p.nln_w + c4), gb = *(const f32x4*)(p.nln_b + c4);
+              f32x4 y;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) y[e] = (xv[i][e] - mu) * rs * gw[e] + gb[e];
+              *(uint2*)(p.ny + (size_t)row * F_D + c4) = uint2{pack2bf(y[0], y[1]), pack2bf(y[2], y[3])};
+            }
           }
         }
       } else {
@@ -626,13 +667,17 @@ int mlp192_grid(int M, int* n_groups) {
 
 extern "C" int dkd_mlp192_fwd(const float* x1, const float* ln_w, const float* ln_b, float eps, const void* fc1_w, const float* fc1_b,
                               const void* fc2_wt, const float* fc2_b, const float* rowscale, int32_t rows_per_sample, float* x2, void* tap,
-                              void* y2, void* pre, void* h, float* mean, float* rstd, int32_t M, int32_t hidden, void* stream) {
+                              void* y2, void* pre, void* h, float* mean, float* rstd, const float* next_ln_w, const float* next_ln_b,
+                              void* next_y, float* next_mean, float* next_rstd, int32_t M, int32_t hidden, void* stream) {
   DKD_CHECK_ARG(x1 && ln_w && ln_b && fc1_w && fc1_b && fc2_wt && fc2_b && x2, "mlp192_fwd: null operand");
   DKD_CHECK_ARG(M > 0 && hidden > 0 && hidden % 64 == 0 && hidden <= F_MAX_HIDDEN, "mlp192_fwd: hidden=%d must be a multiple of 64, <= %d", hidden,
                 F_MAX_HIDDEN);
   DKD_CHECK_ARG(!rowscale || rows_per_sample > 0, "mlp192_fwd: rowscale needs rows_per_sample");
   const bool save = y2 || pre || h || mean || rstd;
   DKD_CHECK_ARG(!save || (y2 && pre && h && mean && rstd), "mlp192_fwd: the saved activations (y2, pre, h, mean, rstd) come all or none");
+  DKD_CHECK_ARG(!next_y || (next_ln_w && next_ln_b && next_mean && next_rstd && ((uintptr_t)next_y & 7) == 0 && ((uintptr_t)next_ln_w & 15) == 0 &&
+                            ((uintptr_t)next_ln_b & 15) == 0),
+                "mlp192_fwd: the next block's LayerNorm needs its weight, bias, y, mean and rstd");
   DKD_CHECK_ARG((((uintptr_t)x1 | (uintptr_t)x2 | (uintptr_t)ln_w | (uintptr_t)ln_b | (uintptr_t)fc1_w | (uintptr_t)fc2_wt | (uintptr_t)fc1_b |
                   (uintptr_t)fc2_b | (uintptr_t)tap | (uintptr_t)y2 | (uintptr_t)pre | (uintptr_t)h) & 15) == 0,
                 "mlp192_fwd: operands must be 16-byte aligned");
@@ -647,6 +692,7 @@ extern "C" int dkd_mlp192_fwd(const float* x1, const float* ln_w, const float* l
   p.wa = (const bf16_t*)fc1_w; p.wb = (const bf16_t*)fc2_wt;
   p.pre = (uint4*)pre; p.hid_out = (bf16_t*)h; p.in16_out = (bf16_t*)y2; p.rowscale = rowscale;
   p.x1 = x1; p.ln_w = ln_w; p.ln_b = ln_b; p.b1 = fc1_b; p.b2 = fc2_b; p.eps = eps; p.mean = mean; p.rstd = rstd; p.x2 = x2; p.tap = (bf16_t*)tap;
+  p.nln_w = next_ln_w; p.nln_b = next_ln_b; p.ny = (bf16_t*)next_y; p.nmean = next_mean; p.nrstd = next_rstd;
   if (save) hipLaunchKernelGGL((mlp192_kernel<0, true>), dim3(grid), dim3(512), 0, as_stream(stream), p);
   else hipLaunchKernelGGL((mlp192_kernel<0, false>), dim3(grid), dim3(512), 0, as_stream(stream), p);
   DKD_CHECK_LAUNCH("mlp192_fwd");

@@ -56,7 +56,8 @@ class Block(C.Structure):
                                            "qkv_w", "proj_w", "fc1_w", "fc2_w", "qkv_wt", "proj_wt", "fc1_wt", "fc2_wt",
                                            "s1", "s2", "x", "x1", "x2", "y1", "qkv", "o", "y2", "pre", "h", "tap",
                                            "mean1", "rstd1", "mean2", "rstd2", "lse")] + [("fuse_mlp", C.c_int32), ("ln_fold", C.c_int32)] +
-                [(n, C.c_void_p) for n in ("qkv_c", "fc1_c", "stats1", "stats2", "stats_next", "xb")])
+                [(n, C.c_void_p) for n in ("qkv_c", "fc1_c", "stats1", "stats2", "stats_next", "xb")] + [("ln1_ready", C.c_int32)] +
+                [(n, C.c_void_p) for n in ("next_ln1_w", "next_ln1_b", "next_y1", "next_mean1", "next_rstd1")])
 
 
 class BlockGrads(C.Structure):
@@ -90,8 +91,8 @@ _SIGS = {
                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                     C.c_int32, C.c_void_p]),
     "dkd_mlp192_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
-                                 C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
-                                 C.c_int32, C.c_void_p]),
+                                 C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "dkd_mlp192_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                  C.c_int32, C.c_int32, C.c_void_p]),

@@ -191,9 +191,10 @@ def gemm_nt_lnbwd(a, w, x, gamma, mean, rstd, dx, dgamma, dbeta, ws, *, cast_out
 
 
 def mlp192_fwd(x1, ln_w, ln_b, fc1_w, fc1_b, fc2_wt, fc2_b, *, eps=1e-6, rowscale=None, rows_per_sample=0, want_tap=False, save=True,
-               out=None):
+               out=None, next_ln=None):
     """The fused MLP branch of a D = 192 block (include/dkd.h, dkd_mlp192_fwd).  x1 f32 [M, 192]; fc1_w / fc2_wt bf16 [hidden, 192].
-    -> dict(x2, tap, y2, pre, h, mean, rstd): y2 / h padded to a multiple of 16 rows, ``pre`` opaque (fragment-native, for mlp192_bwd)."""
+    -> dict(x2, tap, y2, pre, h, mean, rstd): y2 / h padded to a multiple of 16 rows, ``pre`` opaque (fragment-native, for mlp192_bwd).
+    ``next_ln`` = (weight, bias) of the next block's norm1: also returns next_y (bf16 LayerNorm of x2), next_mean, next_rstd."""
     M, D = x1.shape
     Hd = fc1_w.shape[0]
     assert D == 192 and x1.dtype == F32 and x1.is_contiguous() and fc1_w.dtype == BF16 and fc2_wt.dtype == BF16
@@ -205,9 +206,15 @@ def mlp192_fwd(x1, ln_w, ln_b, fc1_w, fc1_b, fc2_wt, fc2_b, *, eps=1e-6, rowscal
         r.update(y2=torch.empty(Mp, D, device=dev, dtype=BF16), pre=torch.empty(Mp * Hd, device=dev, dtype=BF16),
                  h=torch.empty(Mp, Hd, device=dev, dtype=BF16), mean=torch.empty(M, device=dev, dtype=F32),
                  rstd=torch.empty(M, device=dev, dtype=F32))
+    nw = nb = None
+    if next_ln is not None:
+        nw, nb = next_ln
+        r.update(next_y=torch.empty(M, D, device=dev, dtype=BF16), next_mean=torch.empty(M, device=dev, dtype=F32),
+                 next_rstd=torch.empty(M, device=dev, dtype=F32))
     check(lib().dkd_mlp192_fwd(ptr(x1), ptr(ln_w), ptr(ln_b), eps, ptr(fc1_w), ptr(fc1_b), ptr(fc2_wt), ptr(fc2_b), ptr(rowscale),
                                rows_per_sample, ptr(r["x2"]), ptr(r["tap"]), ptr(r["y2"]), ptr(r["pre"]), ptr(r["h"]), ptr(r["mean"]),
-                               ptr(r["rstd"]), M, Hd, stream()), "mlp192_fwd")
+                               ptr(r["rstd"]), ptr(nw), ptr(nb), ptr(r.get("next_y")), ptr(r.get("next_mean")), ptr(r.get("next_rstd")), M, Hd,
+                               stream()), "mlp192_fwd")
     return r
 
 

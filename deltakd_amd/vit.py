@@ -302,14 +302,16 @@ def _fill_weights(bs: ffi.Block, blk: Block, sh: Shadow, B, N, backward: bool):
         bs.fc1_wt, bs.fc2_wt = sh.get(m.fc1.weight, transposed=True).data_ptr(), sh.get(m.fc2.weight, transposed=True).data_ptr()
 
 
-def _block_forward_train(x, B, N, blk: Block, sh: Shadow, s1, s2, want_tap: bool):
-    """x f32 [B*N, D] -> (x2, tap | None, ctx tuple holding the descriptor and the slabs that back its pointers)."""
+def _block_forward_train(x, B, N, blk: Block, sh: Shadow, s1, s2, want_tap: bool, ln1=None, next_blk=None):
+    """x f32 [B*N, D] -> (x2, tap | None, ctx tuple holding the descriptor and the slabs that back its pointers, handoff).
+    ``ln1`` = (y1, mean1, rstd1) when the previous block's fused MLP kernel has already applied this block's norm1 to x;
+    ``next_blk``: with the fused MLP kernels, the block whose norm1 this one applies to its output -> handoff = its (y1, mean1, rstd1)."""
     M, D = x.shape
     Hd, H = blk.mlp.fc1.out_features, blk.attn.num_heads
     dev = x.device
     # bf16 slab: y1 | qkv | o | y2 | pre | h | tap ; f32 slab: x1 | x2 | mean1 | rstd1 | mean2 | rstd2 | lse
     Mp = (M + 15) // 16 * 16             # the fused MLP kernels store y2 / pre / h in whole 16-row groups
-    sizes16 = [M * D, M * 3 * D, M * D, Mp * D, Mp * Hd, Mp * Hd] + ([M * D] if want_tap else [])
+    sizes16 = [0 if ln1 is not None else M * D, M * 3 * D, M * D, Mp * D, Mp * Hd, Mp * Hd] + ([M * D] if want_tap else [])
     off16, tot = [], 0
     for n in sizes16:
         off16.append(tot)
@@ -328,13 +330,20 @@ def _block_forward_train(x, B, N, blk: Block, sh: Shadow, s1, s2, want_tap: bool
     bs.x, bs.x1, bs.x2 = x.data_ptr(), p32 + off32[0], p32 + off32[1]
     bs.mean1, bs.rstd1, bs.mean2, bs.rstd2, bs.lse = (p32 + off32[i] for i in (2, 3, 4, 5, 6))
     bs.y1, bs.qkv, bs.o, bs.y2, bs.pre, bs.h = (p16 + off16[i] for i in range(6))
+    if ln1 is not None:
+        bs.y1, bs.mean1, bs.rstd1, bs.ln1_ready = ln1[0].data_ptr(), ln1[1].data_ptr(), ln1[2].data_ptr(), 1
+    handoff = None
+    if next_blk is not None and bs.fuse_mlp:
+        handoff = (torch.empty(M, D, device=dev, dtype=BF16), torch.empty(M, device=dev, dtype=F32), torch.empty(M, device=dev, dtype=F32))
+        bs.next_ln1_w, bs.next_ln1_b = next_blk.norm1.weight.data_ptr(), next_blk.norm1.bias.data_ptr()
+        bs.next_y1, bs.next_mean1, bs.next_rstd1 = (t.data_ptr() for t in handoff)
     tap = None
     if want_tap:
         bs.tap = p16 + off16[6]
         tap = slab16[off16[6]:off16[6] + M * D * 2].view(BF16).view(M, D)
     ffi.check(ffi.lib().dkd_blocks_fwd(ffi.C.byref(bs), 1, ffi.stream()), "block_fwd")
     x2 = slab32[off32[1]:off32[1] + M * D * 4].view(F32).view(M, D)
-    return x2, tap, (bs, slab16, slab32, x, s1, s2)
+    return x2, tap, (bs, slab16, slab32, x, s1, s2, ln1), handoff
 
 
 _RUNTIME = weakref.WeakKeyDictionary()      # model -> dict of per-process runtime objects (workspaces, streams, events): never copied
@@ -382,7 +391,7 @@ def wgrad_stream_of(model):
 
 def _block_backward(g, gtap, model, blk: Block, saved):
     """g: f32 [M, D] gradient w.r.t. the block output (overwritten with the input gradient and returned)."""
-    bs, slab16, slab32, x, s1, s2 = saved
+    bs, slab16, slab32, x, s1, s2, ln1 = saved
     _fill_weights(bs, blk, model._shadow, bs.B, bs.N, backward=True)
     side = _wgrad_stream(model, g.device)
     par = 0
@@ -421,6 +430,8 @@ def _block_backward(g, gtap, model, blk: Block, saved):
             ev.record(side)
         rt["wgrad_done"][par] = ev
         slab16.record_stream(side)             # h, y2, o, y1 are read there after this function's caller drops them
+        if ln1 is not None:
+            ln1[0].record_stream(side)         # (y1 handed over by the previous block's fused MLP kernel lives outside the slab)
     return g
 
 
@@ -511,7 +522,16 @@ class _BlockFn(torch.autograd.Function):
     def forward(ctx, x, model, idx, B, N, s1, s2, want_tap):
         blk = model.blocks[idx]
         ctx.set_materialize_grads(False)     # an unused tap must not cost a zero-filled [M, D] gradient
-        x2, tap, saved = _block_forward_train(x, B, N, blk, model._shadow, s1, s2, want_tap)
+        # norm1 of this block may already have been applied by the previous block's fused MLP kernel (handed over through the runtime
+        # dict: keyed by the tensor it belongs to), and this block's kernel does the same for the next one
+        rt = _rt(model)
+        ln1 = rt.pop("ln1_handoff", None)
+        if ln1 is not None and (ln1[0] != idx or ln1[1] != x.data_ptr() or os.environ.get("DKD_NO_LN1_HANDOFF")):
+            ln1 = None
+        nxt = model.blocks[idx + 1] if idx + 1 < len(model.blocks) and not os.environ.get("DKD_NO_LN1_HANDOFF") else None
+        x2, tap, saved, handoff = _block_forward_train(x, B, N, blk, model._shadow, s1, s2, want_tap, ln1[2] if ln1 else None, nxt)
+        if handoff is not None:
+            rt["ln1_handoff"] = (idx + 1, x2.data_ptr(), handoff)
         ctx.model, ctx.idx = model, idx
         ctx.saved = saved
         if tap is None:

@@ -168,10 +168,14 @@ int dkd_gemm_nt_lnbwd(const void* A, const void* W, int32_t M, int32_t K, int32_
  * with Mp = M rounded up to 16 (the kernels store whole 16-row groups without predicates), mean / rstd f32 [M], and `pre`:
  * Mp * hidden bf16 in a FRAGMENT-NATIVE order (per 16-row group and 32-unit step, one uint4 per lane) that only dkd_mlp192_bwd reads.
  * backward: dF bf16 [Mp, 192] and dH bf16 [Mp, hidden] are outputs for the weight-gradient launch (dW2 = dF^T h, dW1 = dH^T y2);
- * ws: dkd_layernorm_bwd_workspace_bytes(M, 192) bytes.  gtap, s1, s2, cast_out, tap may be NULL. */
+ * ws: dkd_layernorm_bwd_workspace_bytes(M, 192) bytes.  gtap, s1, s2, cast_out, tap may be NULL.
+ * next_*: optional (all five or none) -- the NEXT block's norm1 applied to the finished rows of x2 in the same epilogue:
+ * next_y bf16 [M, 192] = LayerNorm(x2; next_ln_w, next_ln_b, eps), next_mean / next_rstd f32 [M]; that block's LayerNorm launch
+ * disappears (DkdBlock.ln1_ready). */
 int dkd_mlp192_fwd(const float* x1, const float* ln_w, const float* ln_b, float eps, const void* fc1_w, const float* fc1_b,
                    const void* fc2_wt, const float* fc2_b, const float* rowscale, int32_t rows_per_sample, float* x2, void* tap, void* y2,
-                   void* pre, void* h, float* mean, float* rstd, int32_t M, int32_t hidden, void* stream);
+                   void* pre, void* h, float* mean, float* rstd, const float* next_ln_w, const float* next_ln_b, void* next_y,
+                   float* next_mean, float* next_rstd, int32_t M, int32_t hidden, void* stream);
 int dkd_mlp192_bwd(float* g, const void* gtap, const float* s2, const float* s1, int32_t rows_per_sample, const void* pre,
                    const void* fc2_wt, const void* fc1_w, const float* x1, const float* ln_w, const float* mean, const float* rstd, void* dF,
                    void* dH, void* cast_out, float* d_ln_w, float* d_ln_b, float* ws, int32_t M, int32_t hidden, void* stream);
@@ -301,6 +305,11 @@ typedef struct {
   const float *qkv_c, *fc1_c;
   float *stats1, *stats2, *stats_next;
   void* xb;                          /* bf16 [M, D]                                                                        */
+  int32_t ln1_ready;                 /* 1: y1 / mean1 / rstd1 already hold norm1(x) -- written by the previous block's fused MLP kernel (its
+                                        next_* outputs): the forward skips the LayerNorm launch                              */
+  const float *next_ln1_w, *next_ln1_b;   /* with fuse_mlp, optional: the next block's norm1 parameters and buffers (see dkd_mlp192_fwd) */
+  void* next_y1;
+  float *next_mean1, *next_rstd1;
 } DkdBlock;
 
 typedef struct {

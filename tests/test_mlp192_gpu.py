@@ -76,8 +76,14 @@ def test_mlp192_fwd_matches_torch(ops, M, Hd, rps, with_scale):
     w2t = w2.t().contiguous()
     sc_rows = sc.repeat_interleave(rps)[:M] if with_scale else torch.ones(M, device=dev())
     ref = forward_ref(x1, ln_w, ln_b, w1, b1, w2, b2, sc_rows)
-    r = ops.mlp192_fwd(x1, ln_w, ln_b, w1, b1, w2t, b2, rowscale=sc if with_scale else None, rows_per_sample=rps, want_tap=True)
+    nw, nb = 1.0 + 0.1 * rnd(D, seed=7), 0.1 * rnd(D, seed=8)                # the NEXT block's norm1, applied in the same epilogue
+    r = ops.mlp192_fwd(x1, ln_w, ln_b, w1, b1, w2t, b2, rowscale=sc if with_scale else None, rows_per_sample=rps, want_tap=True,
+                       next_ln=(nw, nb))
     torch.cuda.synchronize()
+    ny = F.layer_norm(r["x2"], (D,), nw, nb, 1e-6)
+    close(r["next_y"], ny, 1e-2, "next block's LayerNorm output")
+    close(r["next_mean"], r["x2"].mean(1), 1e-5, "next mean")
+    close(r["next_rstd"], torch.rsqrt(r["x2"].var(1, unbiased=False) + 1e-6), 1e-5, "next rstd")
     close(r["mean"], ref["mean"], 1e-5, "mean")
     close(r["rstd"], ref["rstd"], 1e-5, "rstd")
     close(r["y2"][:M], ref["y2"], 1e-2, "y2")

@@ -369,11 +369,15 @@ def _backward_workspace(model, bs, dev, which=0):
     return ws
 
 
-def _wgrad_stream(model, dev):
+def _wgrad_stream(model, dev, fused_mlp=False):
     """Side stream for the four weight gradients of a block (one grouped launch: ~1.5 short blocks per CU that spend their time in
     the ring fill and in f32 atomics of partial tiles -- latency, not throughput): issued there, the launch overlaps the next
-    block's backward instead of standing between two of its kernels.  DKD_NO_WGRAD_OVERLAP=1 keeps everything on one stream."""
-    if os.environ.get("DKD_NO_WGRAD_OVERLAP"):
+    block's backward instead of standing between two of its kernels.  DKD_NO_WGRAD_OVERLAP=1 keeps everything on one stream.
+    With the fused MLP kernels (one 8-wave workgroup per CU holding 143 KB of LDS) there is nothing to overlap with: a wgrad workgroup
+    and a fused-backward workgroup cannot share a CU, the two launches only delayed each other (in-situ 165 + 177 us against 91 + 100
+    alone), so the weight gradients then go out inline (measured: student-only step 6.60 -> 6.48 ms); DKD_WGRAD_OVERLAP=1 forces the
+    side stream for A/B."""
+    if os.environ.get("DKD_NO_WGRAD_OVERLAP") or (fused_mlp and not os.environ.get("DKD_WGRAD_OVERLAP")):
         return None
     rt = _rt(model)
     st = rt.get("wgrad_side")
@@ -393,7 +397,7 @@ def _block_backward(g, gtap, model, blk: Block, saved):
     """g: f32 [M, D] gradient w.r.t. the block output (overwritten with the input gradient and returned)."""
     bs, slab16, slab32, x, s1, s2, ln1 = saved
     _fill_weights(bs, blk, model._shadow, bs.B, bs.N, backward=True)
-    side = _wgrad_stream(model, g.device)
+    side = _wgrad_stream(model, g.device, bool(bs.fuse_mlp))
     par = 0
     rt = _rt(model)
     if side is not None:

@@ -1734,7 +1734,8 @@ extern "C" int dkd_gemm_nt(const DkdGemm* gp, void* stream) {
   // the remaining rows to the 128 x 128 kernel (a second call on the row range behind them).
   const bool fast3w = vec_ok && g.epi == (DKD_EPI_BIAS | DKD_EPI_RESID | DKD_EPI_OUT_F32) && !g.rowscale && g.amap.rpg == 0 &&
                       g.cmap.rpg == 0 && g.rmap.rpg == 0 && !g.preact && !(g.tap && (g.epi & DKD_EPI_TAP_F32));
-  if (!wide && ring_ok && fast3w && t256 >= 2 * n_cu && t256 < 1024 && g.K >= 1536) {   // fc2: 330 -> 305 us; proj (K = 768): no gain
+  static const int split_k_min = getenv("DKD_SPLIT_KMIN") ? atoi(getenv("DKD_SPLIT_KMIN")) : 1536;     // (dev: A/B of proj on this path)
+  if (!wide && ring_ok && fast3w && t256 >= 2 * n_cu && t256 < 1024 && g.K >= split_k_min) {   // fc2: 330 -> 305 us; proj (K = 768): no gain
     const int tn = g.N / 256;
     const int panels1 = (int)((t256 / n_cu) * n_cu / tn);           // whole rounds' worth of 256-row panels
     const int M1 = panels1 * 256;
@@ -1786,6 +1787,22 @@ extern "C" int dkd_gemm_nt(const DkdGemm* gp, void* stream) {
     const bool plain16 = !(g.epi & (DKD_EPI_RESID | DKD_EPI_DGELU | DKD_EPI_OUT_F32)) && !g.tap && !g.preact;
     const bool ident = g.cmap.rpg == 0 && !g.rowscale && (g.epi & DKD_EPI_BIAS);
     const int fast = !(plain16 && ident) ? 0 : (g.epi == DKD_EPI_BIAS ? 1 : (g.epi == (DKD_EPI_BIAS | DKD_EPI_GELU) ? 2 : 0));
+    // dev A/B (DKD_NT256_WN2=1): the bf16-epilogue GEMMs on 256 x 128 tiles, two 4-wave workgroups per CU (ring of 3 units each) -- one
+    // workgroup's epilogue can run under the other's K loop, at 85 instead of 128 FLOP per byte through the LDS-DMA path
+    static const int wn2_env = getenv("DKD_NT256_WN2") ? atoi(getenv("DKD_NT256_WN2")) : 0;
+    if (wn2_env && (fast == 1 || fast == 2) && g.N % 128 == 0) {
+      const int tn128 = g.N / 128;
+      int cg2 = (long)g.N * g.K * 2 > (3L << 20) && tn128 % 2 == 0 ? 2 : 1;
+      if (cg_env > 0 && tn128 % cg_env == 0 && 8 % cg_env == 0) cg2 = cg_env;
+      const int nt2 = (cdiv(g.M, 256) * tn128) | (cg2 << 24);
+      const dim3 grid2(2 * n_cu);
+      if (fast == 1 && g.ln_stats) hipLaunchKernelGGL((gemm_nt256_kernel<DKD_NT256_ABL, 0, 2, 1, true>), grid2, dim3(256), 0, as_stream(stream), g, nt2);
+      else if (fast == 2 && g.ln_stats) hipLaunchKernelGGL((gemm_nt256_kernel<DKD_NT256_ABL, 0, 2, 2, true>), grid2, dim3(256), 0, as_stream(stream), g, nt2);
+      else if (fast == 1) hipLaunchKernelGGL((gemm_nt256_kernel<DKD_NT256_ABL, 0, 2, 1>), grid2, dim3(256), 0, as_stream(stream), g, nt2);
+      else hipLaunchKernelGGL((gemm_nt256_kernel<DKD_NT256_ABL, 0, 2, 2>), grid2, dim3(256), 0, as_stream(stream), g, nt2);
+      DKD_CHECK_LAUNCH("gemm_nt256 (256 x 128)");
+      return DKD_OK;
+    }
     if (fast == 1 && g.ln_stats) hipLaunchKernelGGL((gemm_nt256_kernel<DKD_NT256_ABL, 24, 4, 1, true>), grid, dim3(512), 0, as_stream(stream), g, n_tiles);
     else if (fast == 2 && g.ln_stats) hipLaunchKernelGGL((gemm_nt256_kernel<DKD_NT256_ABL, 24, 4, 2, true>), grid, dim3(512), 0, as_stream(stream), g, n_tiles);
     else if (g.ln_stats) {

@@ -5,7 +5,7 @@ Per kernel symbol (template arguments of the ring kernels dropped): mean KiB per
 bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 -- on gfx950 FETCH_SIZE reports half of a 16-B/lane coalesced stream,
 WRITE_SIZE is exact (MI355X_MICROARCH.md, HBM / rocprofv3 section).
 """
-import collections, csv, glob, json, os, re, sys
+import collections, csv, glob, json, os, re, subprocess, sys
 
 root, config, out = sys.argv[1], sys.argv[2], sys.argv[3]
 KEYS = ("gemm_nt_kernel<64", "gemm_nt_kernel<128", "gemm_nt256_kernel", "gemm_tn_kernel", "gemm_tn192g_kernel", "gemm_tn192d_kernel", "gemm_tn192_kernel", "attn_fwd_ring_kernel",
@@ -38,6 +38,9 @@ res = {"_how": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes
                "over all dispatches of the kernel; bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950: FETCH_SIZE reports 1/2 of a "
                "16-B/lane coalesced stream, WRITE_SIZE exact; MI355X_MICROARCH.md section HBM). Memory-side requests include "
                "Infinity-Cache hits.",
+       "_source": "tools_dev/collect_profiles.sh -> tools_dev/summarize_pmc.py " + " ".join(sys.argv[1:]),
+       "_commit": (subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or
+                   os.environ.get("DKD_COMMIT") or None),
        config: {k: (2 * v.get("FETCH_SIZE", 0.0) + v.get("WRITE_SIZE", 0.0)) * 1024 for k, v in raw.items()},
        "_raw_KiB": raw}
 json.dump(res, open(out, "w"), indent=1)

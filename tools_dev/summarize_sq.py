@@ -6,6 +6,10 @@ Per kernel (mean per dispatch): the raw counters, and
   mfma_busy_frac   = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 * 1024)     (1024 = 256 CUs x 4 SIMDs, each with one MFMA pipe;
                      the counter counts pipe-busy cycles: 16 per v_mfma_f32_16x16x32_bf16)
   wait_frac, issue_stall_frac, active_frac = SQ_WAIT_ANY, SQ_WAIT_INST_ANY, SQ_ACTIVE_INST_ANY over SQ_WAVE_CYCLES
+The quotient GRBM_GUI_ACTIVE / 8 / duration reads high on short dispatches (the counter window is wider than the kernel: 4.8 GHz
+"clocks" for 40-us kernels in round 2), and mfma_busy_frac is understated by the same factor: for dispatches under 100 us both are
+reported as null with "short_dispatch": true, and mfma_busy_frac_at_2p1ghz (pipe-busy cycles over duration x 2.1 GHz x 1024, the clock
+the long kernels hold) is given instead.
 """
 import collections, csv, glob, json, os, sys
 
@@ -44,8 +48,12 @@ for k in sorted(set(mf) | set(wv), key=lambda k: -(mf.get(k, {}).get("GRBM_GUI_A
         m = mf[k]
         cyc = m["GRBM_GUI_ACTIVE"] / 8.0
         e.update(m)
-        e["clock_ghz"] = cyc / m["duration_ns_under_pmc"] if m["duration_ns_under_pmc"] else None
-        e["mfma_busy_frac"] = m["SQ_VALU_MFMA_BUSY_CYCLES"] / (cyc * 1024.0) if cyc else None
+        short = m["duration_ns_under_pmc"] < 100e3
+        e["short_dispatch"] = short
+        e["clock_ghz"] = None if short or not m["duration_ns_under_pmc"] else cyc / m["duration_ns_under_pmc"]
+        e["mfma_busy_frac"] = None if short or not cyc else m["SQ_VALU_MFMA_BUSY_CYCLES"] / (cyc * 1024.0)
+        e["mfma_busy_frac_at_2p1ghz"] = (m["SQ_VALU_MFMA_BUSY_CYCLES"] / (m["duration_ns_under_pmc"] * 2.1 * 1024.0)
+                                         if m["duration_ns_under_pmc"] else None)
     if k in wv:
         w = wv[k]
         e.update({c: w[c] for c in w if c.startswith("SQ_")})

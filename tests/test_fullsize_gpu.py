@@ -474,6 +474,27 @@ def test_teacher_forward_with_folded_layernorms(models, monkeypatch):
     assert not torch.equal(taps_f[11], taps_u[11]), "the two runs were meant to take different kernels"
 
 
+def test_vit_large_teacher_with_folded_layernorms(monkeypatch):
+    """The same on BASELINE config 5's teacher (vit_large_patch16_224: D = 1024, hidden 4096, depth 24, ONE prefix token) at 128 images:
+    fc2 (N = 1024, K = 4096) takes the whole-rounds + tail split with both kernels emitting, proj the 128-row kernel, qkv / fc1 the
+    folded wide kernel; taps of blocks 0, 1, 2 (what wasskd reads) and the logits against the unfolded path."""
+    from deltakd_amd import vit
+    Bv, Nv = 128, 197
+    assert vit.ln_fold_supported(Bv * Nv, 1024, 4096)
+    torch.manual_seed(9)
+    t = vit.create_model("vit_large_patch16_224", num_classes=1000).to(DEV).eval()
+    x = rnd(Bv, 3, 224, 224, seed=71)
+    with torch.no_grad():
+        z_f, taps_f = t.forward_with_taps(x, (0, 1, 2))
+        monkeypatch.setenv("DKD_NO_LN_FOLD", "1")
+        z_u, taps_u = t.forward_with_taps(x, (0, 1, 2))
+    torch.cuda.synchronize()
+    assert rel(z_f, z_u) < 2e-2, rel(z_f, z_u)
+    for i in (0, 1, 2):
+        assert rel(taps_f[i], taps_u[i]) < 2e-2, (i, rel(taps_f[i], taps_u[i]))
+    assert not torch.equal(z_f, z_u)
+
+
 REAL = {  # kind -> (student, teacher, batch): BASELINE.json configs 2, 4, 3 and 5
     "soft": ("deit_tiny_distilled_patch16_224", "deit_small_distilled_patch16_224", 4),
     "lrkd": ("deit_tiny_patch16_224", "deit_base_distilled_patch16_224", 4),

@@ -161,6 +161,29 @@ __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
   }
 }
 
+// The same update for parameters that may receive NO gradient in a step (torch.optim.AdamW skips ``p.grad is None`` entirely: no
+// moment decay, no weight decay, no step count): state[0] = largest |g| over the unit this segment belongs to (0: nothing wrote a
+// gradient -> skip), state[1] = the unit's own step count, already advanced by the caller for this step.
+__global__ void adamw_gated_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                   bf16_t* __restrict__ pb, long n, float lr, float b1, float b2, float eps, float wd,
+                                   const float* __restrict__ state) {
+  if (state[0] == 0.f) return;
+  const float step = state[1];
+  const float bc1 = 1.f - powf(b1, step), bc2_sqrt = sqrtf(1.f - powf(b2, step));
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float gi = g[i];
+    float pi = p[i] * (1.f - lr * wd);
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    pi -= (lr / bc1) * (mi / denom);
+    p[i] = pi;
+    if (pb) pb[i] = f2bf(pi);
+  }
+}
+
 // Mixup / CutMix on a batch resident in HBM (timm Mixup mode='batch' [3P], reached from tools/engine.py:16-18): sample b is
 // mixed with sample B-1-b.  The pair is processed by ONE thread per element so the update is in place and race-free.
 //   mixup : x_b <- lam x_b + (1-lam) x_{B-1-b}        cutmix: the box [yl,yh) x [xl,xh) of x_b <- that of x_{B-1-b}
@@ -302,6 +325,15 @@ extern "C" int dkd_adamw_step(float* p, const float* g, float* m, float* v, void
   hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n, 256, 8192)), dim3(256), 0, as_stream(stream), p, g, m, v, (bf16_t*)p_bf16, (long)n, lr, beta1,
                      beta2, eps, weight_decay, bc1, bc2s, grad_scale);
   DKD_CHECK_LAUNCH("adamw");
+  return DKD_OK;
+}
+
+extern "C" int dkd_adamw_step_gated(float* p, const float* g, float* m, float* v, void* p_bf16, int64_t n, float lr, float beta1, float beta2,
+                                    float eps, float weight_decay, const float* state, void* stream) {
+  DKD_CHECK_ARG(p && g && m && v && state && n > 0, "adamw_gated: bad arguments");
+  hipLaunchKernelGGL(adamw_gated_kernel, dim3(grid_for(n, 256, 8192)), dim3(256), 0, as_stream(stream), p, g, m, v, (bf16_t*)p_bf16, (long)n, lr,
+                     beta1, beta2, eps, weight_decay, state);
+  DKD_CHECK_LAUNCH("adamw_gated");
   return DKD_OK;
 }
 

@@ -144,6 +144,8 @@ _SIGS = {
                                    C.c_void_p, C.c_void_p, C.c_void_p]),
     "dkd_adamw_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float,
                                  C.c_float, C.c_float, C.c_float, C.c_int32, C.c_float, C.c_void_p]),
+    "dkd_adamw_step_gated": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float,
+                                       C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p]),
 }
 EXPORTS = tuple(_SIGS)
 

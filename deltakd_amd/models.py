@@ -172,6 +172,14 @@ def attach_aux(student, teacher, distillation_type, args=None):
         student.curkd_align_last = _linear_default(ds, dt)
         student.mask_token = nn.Parameter(torch.zeros(1, 1, dt))
         student.generation = Generation(dt)
+        # each stage receives gradients only in its epochs (model/loss.py:376-420); outside them torch.optim.AdamW skips its parameters
+        # (grad None): FusedAdamW does the same per unit (deltakd_amd.optim)
+        for unit, mods in (("curkd_early", [student.curkd_align_early]), ("curkd_mid", [student.curkd_align_mid]),
+                           ("curkd_last", [student.curkd_align_last, student.generation])):
+            for m in mods:
+                for p in m.parameters():
+                    p.dkd_lazy_unit = unit
+        student.mask_token.dkd_lazy_unit = "curkd_last"
     return student
 
 

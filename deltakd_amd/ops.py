@@ -358,6 +358,13 @@ def adamw_step(p, g, m, v, p_bf16, lr, beta1, beta2, eps, wd, step, grad_scale=1
                                stream()), "adamw")
 
 
+def adamw_step_gated(p, g, m, v, p_bf16, lr, beta1, beta2, eps, wd, state):
+    """AdamW on a flat segment that is skipped when its unit received no gradient this step (include/dkd.h, dkd_adamw_step_gated)."""
+    assert state.dtype == F32 and state.numel() == 2
+    check(lib().dkd_adamw_step_gated(ptr(p), ptr(g), ptr(m), ptr(v), ptr(p_bf16), p.numel(), lr, beta1, beta2, eps, wd, ptr(state), stream()),
+          "adamw_step_gated")
+
+
 def jacobi_eigh(A, sweeps=10):
     """A f32 [batch, n, n] symmetric (n <= 128) -> (evals [batch, n] descending, evecs [batch, n, n], columns sorted alike)."""
     assert A.dtype == F32 and A.dim() == 3 and A.shape[1] == A.shape[2]

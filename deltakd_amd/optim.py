@@ -42,6 +42,8 @@ class FusedAdamW(torch.optim.Optimizer):
         self._flat = []
         self._where = {}               # id(param) -> (flat index, start, end) inside the flat buffers
         self._step = 0
+        self._units = {}               # lazy unit -> device f32 [2]: (largest |g| this step, the unit's own step count)
+        self._unit_segs = {}           # lazy unit -> [(flat index, start, end)]
         self.grad_sync = None          # set by deltakd_amd.ddp: called with the flat grad buffers before the update
         self._synced = False           # gradients of the current iteration already averaged (sync_grads() ran ahead of step())
         self._flatten()
@@ -58,12 +60,19 @@ class FusedAdamW(torch.optim.Optimizer):
             dev = ps[0].device
             if dev.type != "cuda":
                 raise RuntimeError("FusedAdamW needs parameters on an MI355X device (move the model first; no CPU path)")
+            # Parameters that receive a gradient only in some steps (``p.dkd_lazy_unit`` = a name shared by the parameters that are used
+            # together: curkd's align stages, model/loss.py:362-420) go to the END of the group's buffer, unit by unit.  torch.optim.AdamW
+            # skips a parameter whose gradient is None altogether (no moment decay, no weight decay, its own step count); the kernels here
+            # write into pre-allocated zero-filled gradients, so "nothing was written" is detected per unit on the device and those
+            # segments are skipped by the gated kernel (dkd_adamw_step_gated).
+            ps = sorted(ps, key=lambda q: (getattr(q, "dkd_lazy_unit", None) is not None, getattr(q, "dkd_lazy_unit", None) or ""))
             sizes = [(p.numel() + 7) // 8 * 8 for p in ps]          # keep every f32 AND bf16 view 16-byte aligned
             total = sum(sizes)
             fp = torch.zeros(total, device=dev, dtype=F32)
             fg = torch.zeros(total, device=dev, dtype=F32)
             fb = torch.zeros(total, device=dev, dtype=BF16)
             off = 0
+            segments = []                                           # [start, end, unit | None], consecutive
             for p, n in zip(ps, sizes):
                 k = p.numel()
                 fp[off:off + k].copy_(p.detach().reshape(-1))
@@ -75,9 +84,18 @@ class FusedAdamW(torch.optim.Optimizer):
                 bound[id(p)] = fb[off:off + k]
                 bound_params.append(p)
                 self._where[id(p)] = (len(self._flat), off, off + n)
+                unit = getattr(p, "dkd_lazy_unit", None)
+                if segments and segments[-1][2] == unit:
+                    segments[-1][1] = off + n
+                else:
+                    segments.append([off, off + n, unit])
                 off += n
             fb.copy_(fp)
-            self._flat.append(dict(p=fp, g=fg, bf=fb, m=torch.zeros_like(fp), v=torch.zeros_like(fp)))
+            for s0, e0, unit in segments:
+                if unit is not None:
+                    self._units.setdefault(unit, torch.zeros(2, device=dev, dtype=F32))
+                    self._unit_segs.setdefault(unit, []).append((len(self._flat), s0, e0))
+            self._flat.append(dict(p=fp, g=fg, bf=fb, m=torch.zeros_like(fp), v=torch.zeros_like(fp), segments=segments))
         for sh in self._shadows:
             sh.bind_flat(bound, bound_params)
             sh.optimizer_stepped(bf16_fresh=True)
@@ -136,12 +154,20 @@ class FusedAdamW(torch.optim.Optimizer):
         self.sync_grads()
         self._synced = False
         self._step += 1
+        for unit, state in self._units.items():           # did anything write a gradient for this unit?  (device side: no host sync)
+            gate = torch.stack([self._flat[i]["g"][s0:e0].abs().amax() for i, s0, e0 in self._unit_segs[unit]]).amax()
+            state[0] = gate
+            state[1] += (gate > 0).to(F32)
         for group, f in zip(self.param_groups, self._flat):
             if f is None:
                 continue
             b1, b2 = group["betas"]
-            ops.adamw_step(f["p"], f["g"], f["m"], f["v"], f["bf"], group["lr"], b1, b2, group["eps"], group["weight_decay"],
-                           self._step)
+            for s0, e0, unit in f["segments"]:
+                seg = [f[k][s0:e0] for k in ("p", "g", "m", "v", "bf")]
+                if unit is None:
+                    ops.adamw_step(*seg, group["lr"], b1, b2, group["eps"], group["weight_decay"], self._step)
+                else:
+                    ops.adamw_step_gated(*seg, group["lr"], b1, b2, group["eps"], group["weight_decay"], self._units[unit])
         for sh in self._shadows:
             sh.optimizer_stepped(bf16_fresh=True)
             if hasattr(sh, "refresh_transposed"):
@@ -153,14 +179,17 @@ class FusedAdamW(torch.optim.Optimizer):
 
     def state_dict(self):
         state, groups, idx = {}, [], 0
+        unit_steps = {u: int(st[1].item()) for u, st in self._units.items()}       # (host sync: checkpoint time only)
         for group, f in zip(self.param_groups, self._flat):
             ids = []
             for p in group["params"]:
                 w = self._where.get(id(p))
-                if w is not None and self._step > 0:
+                unit = getattr(p, "dkd_lazy_unit", None)
+                step = unit_steps[unit] if unit in unit_steps else self._step
+                if w is not None and step > 0:
                     _, s, _ = w
                     k = p.numel()
-                    state[idx] = {"step": torch.tensor(float(self._step)),
+                    state[idx] = {"step": torch.tensor(float(step)),
                                   "exp_avg": f["m"][s:s + k].view(p.shape).clone(),
                                   "exp_avg_sq": f["v"][s:s + k].view(p.shape).clone()}
                 ids.append(idx)
@@ -191,7 +220,11 @@ class FusedAdamW(torch.optim.Optimizer):
                     raise ValueError(f"optimizer state {idx}: shape {tuple(st['exp_avg'].shape)} does not match the parameter {tuple(p.shape)}")
                 f["m"][s:s + k].copy_(st["exp_avg"].reshape(-1))
                 f["v"][s:s + k].copy_(st["exp_avg_sq"].reshape(-1))
-                steps.add(int(float(st["step"])))
+                unit = getattr(p, "dkd_lazy_unit", None)
+                if unit in self._units:
+                    self._units[unit][1] = float(st["step"])        # a lazy unit keeps its own count
+                else:
+                    steps.add(int(float(st["step"])))
             for key in ("lr", "betas", "eps", "weight_decay", "initial_lr"):
                 if key in saved:
                     group[key] = tuple(saved[key]) if key == "betas" else saved[key]

@@ -367,6 +367,12 @@ int dkd_lowrank_step(const float* G, float* V, int32_t L, int32_t Dt, int32_t mo
 /* One launch over a flat parameter segment; optionally refreshes the bf16 shadow copy used by the GEMMs. */
 int dkd_adamw_step(float* p, const float* g, float* m, float* v, void* p_bf16, int64_t n, float lr, float beta1, float beta2,
                    float eps, float weight_decay, int32_t step, float grad_scale, void* stream);
+/* The same for a segment of parameters that may receive no gradient in a step (curkd's align stages outside their epochs,
+ * model/loss.py:362-420): torch.optim.AdamW skips ``p.grad is None`` entirely.  state f32 [2] on the device: state[0] = largest |g| of
+ * the unit the segment belongs to this step (0 = nothing wrote a gradient: the launch does nothing), state[1] = that unit's own step
+ * count, already advanced for this step (bias corrections are taken from it). */
+int dkd_adamw_step_gated(float* p, const float* g, float* m, float* v, void* p_bf16, int64_t n, float lr, float beta1, float beta2,
+                         float eps, float weight_decay, const float* state, void* stream);
 
 #ifdef __cplusplus
 }

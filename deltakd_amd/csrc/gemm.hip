@@ -724,7 +724,7 @@ __global__ __launch_bounds__(128 * WN, WN == 4 ? 1 : 2) void gemm_nt256_kernel(c
         for (int i = 0; i < 8; ++i) {
           asm volatile("" : "+v"(stq[i]));          // (requested a tile ago: see request_stats)
           mu8[i] = __uint_as_float(stq[i].x) * invK;
-          rs8[i] = rsqrtf(__uint_as_float(stq[i].y) * invK - mu8[i] * mu8[i] + g.ln_eps);
+          rs8[i] = rsqrtf(fmaxf(__uint_as_float(stq[i].y) * invK - mu8[i] * mu8[i], 0.f) + g.ln_eps);   // (one-pass variance: clamp the rounding)
         }
       }
       constexpr bool FAST3 = FAST == 3;

@@ -69,6 +69,12 @@ def train_one_epoch(student_model, teacher_model, train_loader, criterion, optim
     if args.distillation_type.lower() == "none" or os.environ.get("DKD_NO_LOOKAHEAD"):
         prefetch = None                  # nothing to start early: keep the plain order (next batch fetched after the step)
     group_size = max(1, int(getattr(criterion, "prefetch_group", 1))) if prefetch is not None else 1
+    # Groups in flight (DKD_LOOKAHEAD / criterion.prefetch_depth, default 1).  With one, the teacher's work for batch t+1 is queued behind
+    # the loss of batch t, which waits for the teacher's batch t: a serial chain teacher -> loss -> teacher.  With two, the work queued
+    # behind the loss of batch t is batch t+2's and the teacher stream runs back to back.  Measured at the headline config (round 3,
+    # same box, alternating): 18.06 / 18.08 / 18.05 ms per step for 1 / 2 / 3 -- the two streams time-share the CUs, the chain is not
+    # what bounds the step -- so the default stays at one group (one batch of taps alive).
+    depth = max(1, int(os.environ.get("DKD_LOOKAHEAD", getattr(criterion, "prefetch_depth", 1)))) if prefetch is not None else 1
     args.current_epoch = epoch
     pending = collections.deque()        # fetched batches, in order; with a prefetch hook their teacher work has been started
 
@@ -97,7 +103,7 @@ def train_one_epoch(student_model, teacher_model, train_loader, criterion, optim
 
             loss = criterion(samples, student_logits, student_model, student_feats, targets, args)
 
-            if prefetch is not None and len(pending) < group_size:
+            if prefetch is not None and len(pending) < depth * group_size:
                 start_group()                # between the loss and the backward: the teacher's next group overlaps the student's work
 
             if not isinstance(student_logits, torch.Tensor):
@@ -123,7 +129,8 @@ def train_one_epoch(student_model, teacher_model, train_loader, criterion, optim
 
     narrowed = _narrow_student_taps(student_model, criterion)     # for this epoch only: forward_with_features outside the loop
     try:                                                          # keeps returning every block, as the reference's does
-        start_group()
+        for _ in range(depth):
+            start_group()
         _run_steps()
     finally:
         if narrowed is not None:

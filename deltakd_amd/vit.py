@@ -480,43 +480,60 @@ def _blocks_forward_infer(x, B, N, model, scales, want):
     M, D = x.shape
     Hd = blocks[0].mlp.fc1.out_features
     dev = x.device
-    sizes = [M * D, M * 3 * D, M * D, M * Hd]            # y (LN1 and LN2 outputs alias; with the fold: the bf16 copy of x), qkv, o, h
-    off, tot = [], 0
-    for n in sizes:
-        off.append(tot)
-        tot += _bytes_al(n, 2)
-    slab = torch.empty(tot, device=dev, dtype=torch.uint8)
-    p = slab.data_ptr()
-    arr = (ffi.Block * depth)()
-    taps = [None] * depth
     fold = ln_fold_supported(M, D, Hd) and all(s is None for s in scales)
-    keep = []                                             # folded weights / statistics referenced by the descriptors
-    if fold:
-        stats = torch.zeros(2 * depth, M, 2, device=dev, dtype=F32)
-        keep.append(stats)
-    for i, blk in enumerate(blocks):
+    # The descriptor table, the activation slab and the statistics buffers of a frozen model are the same from call to call: filling 12
+    # descriptors (bf16 shadows, folded weights, ~40 ctypes fields each) cost ~0.28 ms of host time per teacher call, during which both
+    # streams sat idle (kernel trace of round 3).  They are cached per (shape, taps, parameter state); a call only patches the pointers
+    # of the residual stream and the taps.  Reusing the slab across calls is stream-ordered (one teacher call after the other).
+    rt = _rt(model)
+    plist = rt.get("infer_params")
+    if plist is None or plist[0] != model._shadow.generation:
+        plist = rt["infer_params"] = (model._shadow.generation, list(model.parameters()))
+    key = (M, D, Hd, B, N, fold, tuple(sorted(want)), dev, plist[0], tuple((p._version, p.data_ptr()) for p in plist[1]),
+           tuple(None if s is None else s.data_ptr() for s in scales))
+    cached = rt.get("infer_table")
+    if cached is None or cached[0] != key:
+        sizes = [M * D, M * 3 * D, M * D, M * Hd]        # y (LN1 and LN2 outputs alias; with the fold: the bf16 copy of x), qkv, o, h
+        off, tot = [], 0
+        for n in sizes:
+            off.append(tot)
+            tot += _bytes_al(n, 2)
+        slab = torch.empty(tot, device=dev, dtype=torch.uint8)
+        p = slab.data_ptr()
+        arr = (ffi.Block * depth)()
+        keep = [slab]                                     # what the descriptors point to
+        stats = torch.zeros(2 * depth, M, 2, device=dev, dtype=F32) if fold else None
+        for i, blk in enumerate(blocks):
+            bs = arr[i]
+            _fill_weights(bs, blk, model._shadow, B, N, backward=False)
+            bs.s1, bs.s2 = ffi.ptr(scales[2 * i]), ffi.ptr(scales[2 * i + 1])
+            bs.y1 = bs.y2 = p + off[0]
+            bs.qkv, bs.o, bs.h = p + off[1], p + off[2], p + off[3]
+            if fold:
+                bits = 2 | (1 if i > 0 else 0) | (4 if i + 1 < depth else 0)
+                bs.ln_fold, bs.xb = bits, p + off[0]
+                bs.stats1, bs.stats2 = stats[2 * i].data_ptr(), stats[2 * i + 1].data_ptr()
+                if i + 1 < depth:
+                    bs.stats_next = stats[2 * i + 2].data_ptr()
+                if i > 0:
+                    wf, bias, csum = _folded_linear(model, blk.norm1, blk.attn.qkv)
+                    bs.qkv_w, bs.qkv_b, bs.qkv_c = wf.data_ptr(), bias.data_ptr(), csum.data_ptr()
+                    keep.append((wf, bias, csum))
+                wf, bias, csum = _folded_linear(model, blk.norm2, blk.mlp.fc1)
+                bs.fc1_w, bs.fc1_b, bs.fc1_c = wf.data_ptr(), bias.data_ptr(), csum.data_ptr()
+                keep.append((wf, bias, csum))
+        cached = rt["infer_table"] = (key, arr, stats, keep)
+    _, arr, stats, _ = cached
+    if stats is not None:
+        stats.zero_()
+    taps = [None] * depth
+    xp = x.data_ptr()
+    for i in range(depth):
         bs = arr[i]
-        _fill_weights(bs, blk, model._shadow, B, N, backward=False)
-        bs.s1, bs.s2 = ffi.ptr(scales[2 * i]), ffi.ptr(scales[2 * i + 1])
-        bs.x = bs.x1 = bs.x2 = x.data_ptr()
-        bs.y1 = bs.y2 = p + off[0]
-        bs.qkv, bs.o, bs.h = p + off[1], p + off[2], p + off[3]
+        bs.x = bs.x1 = bs.x2 = xp
         if i in want:
             taps[i] = torch.empty(M, D, device=dev, dtype=BF16)
             bs.tap = taps[i].data_ptr()
-        if fold:
-            bits = 2 | (1 if i > 0 else 0) | (4 if i + 1 < depth else 0)
-            bs.ln_fold, bs.xb = bits, p + off[0]
-            bs.stats1, bs.stats2 = stats[2 * i].data_ptr(), stats[2 * i + 1].data_ptr()
-            if i + 1 < depth:
-                bs.stats_next = stats[2 * i + 2].data_ptr()
-            if i > 0:
-                wf, bias, csum = _folded_linear(model, blk.norm1, blk.attn.qkv)
-                bs.qkv_w, bs.qkv_b, bs.qkv_c = wf.data_ptr(), bias.data_ptr(), csum.data_ptr()
-                keep.append((wf, bias, csum))
-            wf, bias, csum = _folded_linear(model, blk.norm2, blk.mlp.fc1)
-            bs.fc1_w, bs.fc1_b, bs.fc1_c = wf.data_ptr(), bias.data_ptr(), csum.data_ptr()
-            keep.append((wf, bias, csum))
     ffi.check(ffi.lib().dkd_blocks_fwd(arr, depth, ffi.stream()), "blocks_fwd")
     return x, taps
 
@@ -694,7 +711,12 @@ class VisionTransformer(nn.Module):
             return [None if p == 0.0 else (keep[i].to(device=device, dtype=F32) / (1.0 - p)).contiguous() for i, p in enumerate(probs)]
         if max(probs) == 0.0:
             return [None] * len(probs)
-        keep_prob = 1.0 - torch.tensor(probs, device=device, dtype=F32)[:, None]
+        # (cached on the device: building it from the host list every step was a pageable host-to-device copy, which torch follows
+        # with a stream synchronise -- the host could never run ahead of the GPU across a step boundary)
+        kp = _rt(self).get("keep_prob")
+        if kp is None or kp[0] != (tuple(probs), device):
+            kp = _rt(self)["keep_prob"] = ((tuple(probs), device), 1.0 - torch.tensor(probs, device=device, dtype=F32)[:, None])
+        keep_prob = kp[1]
         scale = (torch.rand(len(probs), B, device=device) < keep_prob).to(F32) / keep_prob
         return [None if p == 0.0 else scale[i] for i, p in enumerate(probs)]
 

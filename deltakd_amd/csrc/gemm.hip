@@ -1654,8 +1654,9 @@ __global__ __launch_bounds__(256, 2) void gemm_tn192d_kernel(const bf16_t* __res
 // Up to four independent weight gradients in ONE launch (the two of an MLP, the two of an attention branch): each alone is ~1.5
 // blocks per CU that all start and end together, so its ring fill and its atomic epilogue overlap nothing; side by side the blocks
 // of one problem fill in while another's drain.  Block ranges are padded to multiples of 8 so blockIdx % 8 stays the XCD.
+constexpr int TN_GROUP_MAX = 24;        // 24 x 96 B of kernel arguments (the limit is 4 KiB)
 struct TnGroup {
-  TnProb p[4];
+  TnProb p[TN_GROUP_MAX];
   int n;
 };
 __global__ __launch_bounds__(256, 2) void gemm_tn192g_kernel(const TnGroup grp) {
@@ -1912,19 +1913,36 @@ extern "C" int dkd_gemm_nt_lnbwd(const void* A, const void* W, int32_t M, int32_
   return dkd_ln_bwd_reduce(ws, nblk, dgamma, dbeta, LNB_D, stream);
 }
 
-extern "C" int dkd_gemm_tn_group(const DkdTnProblem* probs, int32_t n, void* stream) {
-  DKD_CHECK_ARG(probs && n > 0 && n <= 4, "gemm_tn_group: need 1..4 problems (n=%d)", n);
+namespace {
+// Tile columns the ring kernel would cut problem q into, or 0 when it does not take the shape (same test as tn192d_plan).
+int tn192d_tiles(const DkdTnProblem& q) {
+  const bool wide_b = q.N2 > 128 && q.N2 <= 192;
+  const bool wide_a = !wide_b && q.N1 > 128 && q.N1 <= 192 && q.N2 > 192;
+  if (!(wide_b || wide_a) || q.N1 % 8 || q.N2 % 8 || q.M < 32 * 16) return 0;
+  if ((q.lda % 8) || (q.ldb % 8) || ((uintptr_t)q.A & 15) || ((uintptr_t)q.B & 15)) return 0;
+  return cdiv(wide_b ? q.N1 : q.N2, 128);
+}
+
+int tn_group_launch(const DkdTnProblem* probs, int n, void* stream) {
+  // Every tile of every problem gets the SAME number of M splits, chosen so that the launch is one round of the 512 workgroup slots
+  // (2 per CU): all blocks then stream the same number of 32-row units and end together.  (Round 2 gave every PROBLEM the same block
+  // count: the blocks of a 6-tile gradient ran 3x as long as those of a 2-tile one, and for the second half of the launch a CU held
+  // less than one block.)  With the gradients of several transformer blocks in one launch (dkd_block_wgrad_group) the tiles
+  // themselves supply the parallelism: 114 tiles -> 4 splits, i.e. a quarter of the atomically added partial tiles per gradient.
+  static const int slots_env = getenv("DKD_TN_GROUP_SLOTS") ? atoi(getenv("DKD_TN_GROUP_SLOTS")) : 0;       // (dev: A/B)
+  static const int blocks_env = getenv("DKD_TN_GROUP_BLOCKS") ? atoi(getenv("DKD_TN_GROUP_BLOCKS")) : 0;    // (dev: round 2's rule)
+  int total_tiles = 0;
+  for (int i = 0; i < n; ++i) total_tiles += tn192d_tiles(probs[i]);
+  int splits = total_tiles > 0 ? (slots_env > 0 ? slots_env : 512) / total_tiles : 1;
+  if (splits < 1) splits = 1;
   TnGroup grp;
   grp.n = 0;
   int total = 0;
   for (int i = 0; i < n; ++i) {
     const DkdTnProblem& q = probs[i];
     DKD_CHECK_ARG(q.A && q.B && q.C && q.M > 0 && q.N1 > 0 && q.N2 > 0, "gemm_tn_group: bad problem %d", i);
-    // in a group the other problems supply the parallelism: 192 blocks per problem halve the atomically added partial tiles
-    // (student-only step: 27.0k img/s at 384, 27.8k at 256, 29.1k at 192, 27.6k at 128)
-    // ... and 96 each with four (29.6k / 29.5k / 30.5k / 29.0k img/s at 192 / 128 / 96 / 64)
-    static const int blocks_env = getenv("DKD_TN_GROUP_BLOCKS") ? atoi(getenv("DKD_TN_GROUP_BLOCKS")) : 0;     // (dev: A/B of the split count)
-    if (tn192d_plan(q, &grp.p[grp.n], 1, blocks_env > 0 ? blocks_env : (n > 2 ? 96 : (n > 1 ? 192 : 384)))) {
+    const int t1 = tn192d_tiles(q);
+    if (t1 > 0 && tn192d_plan(q, &grp.p[grp.n], 1, blocks_env > 0 ? blocks_env : t1 * splits)) {
       total += grp.p[grp.n].n_blocks;
       ++grp.n;
     } else {                            // shapes the ring kernel does not take: launched on their own
@@ -1937,6 +1955,18 @@ extern "C" int dkd_gemm_tn_group(const DkdTnProblem* probs, int32_t n, void* str
     DKD_CHECK_LAUNCH("gemm_tn_group");
   }
   return DKD_OK;
+}
+}  // namespace
+
+extern "C" int dkd_gemm_tn_group(const DkdTnProblem* probs, int32_t n, void* stream) {
+  DKD_CHECK_ARG(probs && n > 0 && n <= TN_GROUP_MAX, "gemm_tn_group: need 1..%d problems (n=%d)", TN_GROUP_MAX, n);
+  return tn_group_launch(probs, n, stream);
+}
+
+extern "C" int dkd_block_wgrad_group(const DkdTnProblem* probs, int32_t n, void* stream) {
+  DKD_CHECK_ARG(probs && n > 0 && n <= TN_GROUP_MAX, "block_wgrad_group: need 1..%d problems (n=%d)", TN_GROUP_MAX, n);
+  DkdProbeScope probe(3, 0.0, 0.0, as_stream(stream));      // time of the student block backward; its FLOPs are counted by dkd_block_bwd
+  return tn_group_launch(probs, n, stream);
 }
 
 // M splits of gemm_tn_kernel: the launch is `blocks_per_split x splits` workgroups on 512 slots (2 per CU); its time is

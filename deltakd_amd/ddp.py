@@ -44,6 +44,7 @@ class DataParallel(nn.Module):
             self._plan = self._plan_overlap()
             if self._plan:
                 module._grad_ready_hook = self._on_block_backward
+                module._wgrad_group = 4         # = blocks per bucket: the deferred weight gradients of a bucket's blocks go out together
 
     # -- forward: same call contract as the wrapped model; ``with_taps`` lets forward_with_features go through the wrapper
     def forward(self, x, with_taps=False):

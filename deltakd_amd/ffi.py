@@ -77,6 +77,7 @@ _SIGS = {
     "dkd_gemm_tn": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                               C.c_int32, RowMap, RowMap, C.c_void_p, C.c_void_p]),
     "dkd_gemm_tn_group": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
+    "dkd_block_wgrad_group": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
     "dkd_conv3x3_wgrad": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "dkd_gram": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, RowMap, C.c_void_p]),
     "dkd_attn_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),

@@ -393,23 +393,67 @@ def wgrad_stream_of(model):
     return _rt(model).get("wgrad_side")
 
 
-def _block_backward(g, gtap, model, blk: Block, saved):
-    """g: f32 [M, D] gradient w.r.t. the block output (overwritten with the input gradient and returned)."""
+WGRAD_GROUP_MAX = 6           # blocks per deferred weight-gradient launch (4 problems each; dkd_block_wgrad_group takes 24)
+
+
+def wgrad_group_size(model):
+    """Blocks whose weight gradients share one launch.  The student walks its blocks backward and keeps the operands of up to this many
+    alive (one backward workspace each); the flush is ONE dkd_block_wgrad_group: 6 blocks = 114 tiles on 4 M splits instead of 26 per
+    block, one ring fill / atomic tail instead of six (student-only step 6.25 -> see DESIGN).  ``model._wgrad_group`` (data parallel
+    sets 4 = its bucket size, so a bucket's all-reduce starts as soon as its blocks are done) or DKD_WGRAD_GROUP; 1 = inside
+    dkd_block_bwd, as in round 2."""
+    g = int(os.environ.get("DKD_WGRAD_GROUP", getattr(model, "_wgrad_group", WGRAD_GROUP_MAX)))
+    return max(1, min(WGRAD_GROUP_MAX, g))
+
+
+def flush_wgrads(model):
+    """Launch the weight gradients deferred so far (no-op when there are none) and report their blocks to the data-parallel hook."""
+    rt = _rt(model)
+    pend = rt.get("wgrad_pending")
+    if not pend:
+        return
+    rt["wgrad_pending"] = []
+    n = 4 * len(pend)
+    probs = (ffi.TnProblem * n)()
+    k = 0
+    for entry in pend:
+        M = entry["M"]
+        for pa, pb, pc, pcs, n1, n2 in entry["problems"]:
+            q = probs[k]
+            q.A, q.B, q.C, q.a_colsum, q.M, q.N1, q.N2, q.lda, q.ldb, q.ldc = pa, pb, pc, pcs, M, n1, n2, n1, n2, n2
+            q.amap = q.bmap = IDENT
+            k += 1
+    ffi.check(ffi.lib().dkd_block_wgrad_group(ffi.C.cast(probs, ffi.C.c_void_p), n, ffi.stream()), "block wgrad group")
+    hook = getattr(model, "_grad_ready_hook", None)             # data parallel: these blocks' gradients are final now
+    if hook is not None:
+        for entry in pend:
+            if entry["idx"] is not None:
+                hook(entry["idx"])
+
+
+def _block_backward(g, gtap, model, blk: Block, saved, idx=None):
+    """g: f32 [M, D] gradient w.r.t. the block output (overwritten with the input gradient and returned).  Returns (g, deferred):
+    ``deferred`` says the block's weight gradients wait in the model's pending list for flush_wgrads()."""
     bs, slab16, slab32, x, s1, s2, ln1 = saved
     _fill_weights(bs, blk, model._shadow, bs.B, bs.N, backward=True)
     side = _wgrad_stream(model, g.device, bool(bs.fuse_mlp))
     par = 0
     rt = _rt(model)
+    group = wgrad_group_size(model) if side is None else 1
+    pend = rt.setdefault("wgrad_pending", [])
     if side is not None:
         par = rt["bwd_parity"] = 1 - rt["bwd_parity"]
         done = rt["wgrad_done"][par]
         if done is not None:                       # the weight gradients that last read this workspace (two blocks ago)
             torch.cuda.current_stream().wait_event(done)
+    elif group > 1:
+        par = ("group", len(pend))                 # one workspace per pending block: dF / dH / dF2 / dqkv live until the flush
     ws = _backward_workspace(model, bs, g.device, par)
     gr = ffi.BlockGrads()
     ffi.check(ffi.lib().dkd_block_bwd_workspace_carve(ws.data_ptr(), bs.B, bs.N, bs.D, bs.hidden, ffi.C.byref(gr)), "bwd_workspace")
     gr.g, gr.gtap = g.data_ptr(), ffi.ptr(gtap)
-    gr.defer_wgrad = 1 if side is not None else 0
+    defer = side is not None or (group > 1 and bool(gr.dF2))
+    gr.defer_wgrad = 1 if defer else 0
     a, m = blk.attn, blk.mlp
     gr.d_ln1_w, gr.d_ln1_b = ensure_grad(blk.norm1.weight).data_ptr(), ensure_grad(blk.norm1.bias).data_ptr()
     gr.d_ln2_w, gr.d_ln2_b = ensure_grad(blk.norm2.weight).data_ptr(), ensure_grad(blk.norm2.bias).data_ptr()
@@ -418,25 +462,30 @@ def _block_backward(g, gtap, model, blk: Block, saved):
     gr.d_fc1_w, gr.d_fc1_b = ensure_grad(m.fc1.weight).data_ptr(), ensure_grad(m.fc1.bias).data_ptr()
     gr.d_fc2_w, gr.d_fc2_b = ensure_grad(m.fc2.weight).data_ptr(), ensure_grad(m.fc2.bias).data_ptr()
     ffi.check(ffi.lib().dkd_block_bwd(ffi.C.byref(bs), ffi.C.byref(gr), ffi.stream()), "block_bwd")
-    if side is not None:
-        M, D, Hd = bs.B * bs.N, bs.D, bs.hidden
-        probs = (ffi.TnProblem * 4)()
-        for q, (pa, pb, pc, pcs, n1, n2) in zip(probs, ((gr.dF, bs.h, gr.d_fc2_w, gr.d_fc2_b, D, Hd), (gr.dH, bs.y2, gr.d_fc1_w, gr.d_fc1_b, Hd, D),
-                                                        (gr.dF2, bs.o, gr.d_proj_w, gr.d_proj_b, D, D),
-                                                        (gr.dqkv, bs.y1, gr.d_qkv_w, gr.d_qkv_b, 3 * D, D))):
-            q.A, q.B, q.C, q.a_colsum, q.M, q.N1, q.N2, q.lda, q.ldb, q.ldc = pa, pb, pc, pcs, M, n1, n2, n1, n2, n2
-            q.amap = q.bmap = IDENT
-        cur = torch.cuda.current_stream()
-        side.wait_stream(cur)
-        with torch.cuda.stream(side):
-            ffi.check(ffi.lib().dkd_gemm_tn_group(ffi.C.cast(probs, ffi.C.c_void_p), 4, ffi.stream()), "block wgrad")
-            ev = rt["wgrad_events"][par]
-            ev.record(side)
-        rt["wgrad_done"][par] = ev
-        slab16.record_stream(side)             # h, y2, o, y1 are read there after this function's caller drops them
-        if ln1 is not None:
-            ln1[0].record_stream(side)         # (y1 handed over by the previous block's fused MLP kernel lives outside the slab)
-    return g
+    if not defer:
+        return g, False
+    M, D, Hd = bs.B * bs.N, bs.D, bs.hidden
+    problems = ((gr.dF, bs.h, gr.d_fc2_w, gr.d_fc2_b, D, Hd), (gr.dH, bs.y2, gr.d_fc1_w, gr.d_fc1_b, Hd, D),
+                (gr.dF2, bs.o, gr.d_proj_w, gr.d_proj_b, D, D), (gr.dqkv, bs.y1, gr.d_qkv_w, gr.d_qkv_b, 3 * D, D))
+    if side is None:
+        # (slab16 / ln1 hold h, y2, o, y1; kept alive here until the flush has been enqueued -- same stream, so that is enough)
+        pend.append({"M": M, "problems": problems, "idx": idx, "keep": (slab16, ln1, ws, bs)})
+        return g, True
+    probs = (ffi.TnProblem * 4)()
+    for q, (pa, pb, pc, pcs, n1, n2) in zip(probs, problems):
+        q.A, q.B, q.C, q.a_colsum, q.M, q.N1, q.N2, q.lda, q.ldb, q.ldc = pa, pb, pc, pcs, M, n1, n2, n1, n2, n2
+        q.amap = q.bmap = IDENT
+    cur = torch.cuda.current_stream()
+    side.wait_stream(cur)
+    with torch.cuda.stream(side):
+        ffi.check(ffi.lib().dkd_block_wgrad_group(ffi.C.cast(probs, ffi.C.c_void_p), 4, ffi.stream()), "block wgrad")
+        ev = rt["wgrad_events"][par]
+        ev.record(side)
+    rt["wgrad_done"][par] = ev
+    slab16.record_stream(side)             # h, y2, o, y1 are read there after this function's caller drops them
+    if ln1 is not None:
+        ln1[0].record_stream(side)         # (y1 handed over by the previous block's fused MLP kernel lives outside the slab)
+    return g, False
 
 
 def ln_fold_supported(M, D, hidden):
@@ -573,14 +622,24 @@ class _BlockFn(torch.autograd.Function):
         g = g.contiguous()
         if g.dtype != F32:
             g = g.float()
-        gin = _block_backward(g, gtap, ctx.model, ctx.model.blocks[ctx.idx], ctx.saved)
+        model = ctx.model
+        gin, deferred = _block_backward(g, gtap, model, model.blocks[ctx.idx], ctx.saved, ctx.idx)
         ctx.saved = None
-        side = wgrad_stream_of(ctx.model)
+        side = wgrad_stream_of(model)
         if side is not None and ctx.idx == 0:       # last block of the backward walk: everything downstream (embedding backward,
             torch.cuda.current_stream().wait_stream(side)   # optimizer) sees all weight gradients
-        hook = getattr(ctx.model, "_grad_ready_hook", None)     # data parallel: this block's gradients are final
-        if hook is not None:
-            hook(ctx.idx)
+        if deferred:
+            rt = _rt(model)
+            if len(rt["wgrad_pending"]) >= wgrad_group_size(model) or ctx.idx == 0:
+                flush_wgrads(model)                 # (calls the data-parallel hook for every block it covers)
+            elif len(rt["wgrad_pending"]) == 1:
+                # safety net for a backward pass that never reaches block 0 (a frozen prefix, a partial graph): whatever is still
+                # pending goes out when the autograd engine finishes this pass (a no-op after a regular flush)
+                torch.autograd.Variable._execution_engine.queue_callback(lambda model=model: flush_wgrads(model))
+        else:
+            hook = getattr(model, "_grad_ready_hook", None)     # data parallel: this block's gradients are final
+            if hook is not None:
+                hook(ctx.idx)
         return gin, None, None, None, None, None, None, None
 
 
@@ -746,6 +805,7 @@ class VisionTransformer(nn.Module):
         grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
         scales = self._droppath_scales(B, img.device)
         if grad:
+            _rt(self).pop("wgrad_pending", None)      # (only non-empty here after a backward pass that died half-way: stale, dropped)
             x = _EmbedFn.apply(self.pos_embed, self, img)
             for i in range(depth):
                 x, tap = _BlockFn.apply(x, self, i, B, N, scales[2 * i], scales[2 * i + 1], i in want)

@@ -117,9 +117,11 @@ int dkd_conv3x3_wgrad(const void* dY, const void* x, float* dW, float* dbias, in
  * N = 768). */
 int dkd_gram(const void* A, float* C, int32_t M, int32_t N, int32_t lda, int32_t ldc, DkdRowMap amap, void* stream);
 
-/* Up to four independent weight gradients in one launch (the two Linear layers of an MLP, or proj + qkv): same arithmetic as
- * dkd_gemm_tn per problem, but their blocks share the GPU, so one problem's ring fill and atomic epilogue overlap another's
- * main loop.  Problems the grouped kernel does not take (see gemm.hip) are launched on their own. */
+/* Up to 24 independent weight gradients in one launch (the two Linear layers of an MLP, proj + qkv, all four of a transformer block,
+ * or those of several blocks): same arithmetic as dkd_gemm_tn per problem, but their blocks share the GPU -- every 128-column tile of
+ * every problem gets the same number of M splits, chosen so that the launch is one round of workgroups that end together; the more
+ * tiles, the fewer atomically added partial tiles per gradient.  Problems the grouped kernel does not take (see gemm.hip) are
+ * launched on their own. */
 typedef struct DkdTnProblem {
   const void* A;
   const void* B;
@@ -129,6 +131,11 @@ typedef struct DkdTnProblem {
   DkdRowMap amap, bmap;
 } DkdTnProblem;
 int dkd_gemm_tn_group(const DkdTnProblem* problems, int32_t n, void* stream);
+/* The same launch for the weight gradients a caller deferred from dkd_block_bwd (DkdBlockGrads.defer_wgrad) -- typically those of
+ * SEVERAL consecutive blocks at once (the student walks its blocks backward and flushes every six: 24 problems, 114 tiles, 4 M splits
+ * instead of 26, one ring fill / atomic tail instead of six).  Autograd's accumulation of the weight gradients of nn.Linear
+ * (tools/engine.py:61-62 -> torch.autograd) is what it replaces; the time is booked under the block-backward probe scope. */
+int dkd_block_wgrad_group(const DkdTnProblem* problems, int32_t n, void* stream);
 
 /* ---------------------------------------------------------------- attention ([3P] F.scaled_dot_product_attention) */
 /* qkv bf16 [B, N, 3, H, 64] (the fused qkv Linear output, no head-split copy); out bf16 [B, N, H*64];
@@ -320,9 +327,9 @@ typedef struct {
   void* dT;                          /* bf16 workspace [M, D]                                                            */
   float* ln_ws;                      /* f32 scratch, 2 * D * ceil(M / 64) floats, for the LayerNorm backward partial sums; or NULL */
   void* dF2;                         /* second bf16 [M, D] workspace or NULL: with it all four weight gradients are one launch   */
-  int32_t defer_wgrad;               /* 1 (needs dF2): do NOT launch the four weight gradients; the caller issues them itself (one
-                                        dkd_gemm_tn_group over dF/h, dH/y2, dF2/o, dqkv/y1) -- e.g. on another stream, so that this
-                                        latency-bound launch (f32 atomics of 384 partial tiles) overlaps the next block's backward */
+  int32_t defer_wgrad;               /* 1 (needs dF2): do NOT launch the four weight gradients; the caller issues them itself
+                                        (dkd_block_wgrad_group over dF/h, dH/y2, dF2/o, dqkv/y1, for one block or for several
+                                        whose workspaces it keeps alive until then) */
 } DkdBlockGrads;
 
 int dkd_blocks_fwd(const DkdBlock* blocks, int32_t n_blocks, void* stream);

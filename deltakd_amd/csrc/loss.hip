@@ -54,7 +54,11 @@ __global__ __launch_bounds__(256) void logit_loss_kernel(const float* __restrict
     else gr = p - ((c == lab ? 1.f - smoothing : 0.f) + smoothing / C);
     dz[(size_t)row * C + c] = w_base * gr * invB;
   }
-  if (lane == 0) atomicAdd(&losses[0], lb * invB);
+  if (lane == 0) {
+    atomicAdd(&losses[0], lb * invB);
+    atomicAdd(&losses[2], w_base * lb * invB);     // [2] the weighted total, [3] / [4] its two addends: no scalar kernels downstream
+    atomicAdd(&losses[3], w_base * lb * invB);
+  }
 
   // ---- logit distillation
   if (kd_mode == 0) return;
@@ -84,7 +88,12 @@ __global__ __launch_bounds__(256) void logit_loss_kernel(const float* __restrict
       dz_kd[(size_t)row * C + c] = gsc * (ps - pt);
     }
     kl = wave_sum(kl);
-    if (lane == 0) atomicAdd(&losses[1], kl * tau * tau / ((float)B * C));
+    if (lane == 0) {
+      const float v = kl * tau * tau / ((float)B * C);
+      atomicAdd(&losses[1], v);
+      atomicAdd(&losses[2], w_kd * v);
+      atomicAdd(&losses[4], w_kd * v);
+    }
   } else {
     // hard: CE(z_kd, argmax z_t); first maximal index like torch.argmax
     float bv = -INFINITY;
@@ -106,7 +115,38 @@ __global__ __launch_bounds__(256) void logit_loss_kernel(const float* __restrict
     for (int c = lane; c < C; c += 64) es += __expf(sr[c] - ms);
     const float ls = ms + __logf(wave_sum(es));
     for (int c = lane; c < C; c += 64) dz_kd[(size_t)row * C + c] = w_kd * invB * (__expf(sr[c] - ls) - (c == bi ? 1.f : 0.f));
-    if (lane == 0) atomicAdd(&losses[1], (ls - sr[bi]) * invB);
+    if (lane == 0) {
+      const float v = (ls - sr[bi]) * invB;
+      atomicAdd(&losses[1], v);
+      atomicAdd(&losses[2], w_kd * v);
+      atomicAdd(&losses[4], w_kd * v);
+    }
+  }
+}
+
+// top-k accuracy (timm.utils.accuracy [3P], tools/engine.py:54-56): one wave per row counts the logits that beat the label's
+// (larger, or equal at a lower index: the order torch.topk's sorted output lists them in); the row is correct at k if fewer than k do.
+// out[i] += 100 / B for every row correct at ks[i].
+__global__ __launch_bounds__(256) void topk_correct_kernel(const float* __restrict__ z, const int64_t* __restrict__ labels, int B, int C,
+                                                           int k0, int k1, int k2, int k3, int nk, float* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= B) return;
+  const float* zr = z + (size_t)row * C;
+  const int lab = (int)labels[row];
+  const float t = zr[lab];
+  int cnt = 0;
+  for (int c = lane; c < C; c += 64) {
+    const float v = zr[c];
+    cnt += (v > t) || (v == t && c < lab);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+  if (lane == 0) {
+    const float w = 100.f / B;
+    const int ks[4] = {k0, k1, k2, k3};
+    for (int i = 0; i < nk; ++i)
+      if (cnt < ks[i]) atomicAdd(&out[i], w);
   }
 }
 
@@ -202,6 +242,20 @@ extern "C" int dkd_logit_loss(const float* z, const float* soft_target, const in
   hipLaunchKernelGGL(logit_loss_kernel, dim3(cdiv(B, 4)), dim3(256), 0, as_stream(stream), z, soft_target, labels, smoothing, kd_mode, z_kd,
                      z_t, tau, w_base, w_kd, losses, dz, dz_kd, B, C);
   DKD_CHECK_LAUNCH("logit_loss");
+  return DKD_OK;
+}
+
+extern "C" int dkd_topk_correct(const float* z, const int64_t* labels, int32_t B, int32_t C, const int32_t* ks, int32_t nk, float* out,
+                                void* stream) {
+  DKD_CHECK_ARG(z && labels && ks && out && B > 0 && C > 0, "topk_correct: null operand");
+  DKD_CHECK_ARG(nk >= 1 && nk <= 4, "topk_correct: 1..4 values of k (nk=%d)", nk);
+  int k[4] = {0, 0, 0, 0};
+  for (int i = 0; i < nk; ++i) {
+    DKD_CHECK_ARG(ks[i] >= 1, "topk_correct: k must be >= 1");
+    k[i] = ks[i];
+  }
+  hipLaunchKernelGGL(topk_correct_kernel, dim3(cdiv(B, 4)), dim3(256), 0, as_stream(stream), z, labels, B, C, k[0], k[1], k[2], k[3], nk, out);
+  DKD_CHECK_LAUNCH("topk_correct");
   return DKD_OK;
 }
 

@@ -120,10 +120,8 @@ def train_one_epoch(student_model, teacher_model, train_loader, criterion, optim
             if model_ema is not None:
                 model_ema.update(student_model)
 
-            metric_logger.update(train_loss=loss.detach())
-            metric_logger.update(train_acc1=acc1.detach())
-            metric_logger.update(train_acc5=acc5.detach())
-            metric_logger.update(train_lr=optimizer.param_groups[0]['lr'])
+            metric_logger.update(train_loss=loss.detach(), train_acc1=acc1.detach(), train_acc5=acc5.detach(),
+                                 train_lr=optimizer.param_groups[0]['lr'])       # (one multi-tensor add for the three device meters)
             if prefetch is None:
                 start_group()
 

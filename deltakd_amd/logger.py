@@ -20,12 +20,23 @@ class SmoothedValue:
         self.count = 0
         self._dev_total = None
 
-    def update(self, value, n=1):
+    def update(self, value, n=1, defer=None):
+        """``defer``: a list that collects (device total, addend) pairs instead of adding here -- MetricLogger.update adds the
+        meters of one call in a single multi-tensor launch."""
         self.deque.append(value)
         self.count += n
         if isinstance(value, torch.Tensor):
-            v = value.detach().float() * n
-            self._dev_total = v.clone() if self._dev_total is None else self._dev_total.add_(v)
+            v = value.detach()
+            if v.dtype != torch.float32:
+                v = v.float()
+            if n != 1:
+                v = v * n
+            if self._dev_total is None:
+                self._dev_total = v.clone()
+            elif defer is not None:
+                defer.append((self._dev_total, v))
+            else:
+                self._dev_total.add_(v)
         else:
             self.total += value * n
 
@@ -61,11 +72,24 @@ class MetricLogger:
         self.printer = printer
 
     def update(self, **kwargs):
+        pend = []
         for k, v in kwargs.items():
             if v is None:
                 continue
             assert isinstance(v, (float, int, torch.Tensor))
-            self.meters[k].update(v)
+            self.meters[k].update(v, defer=pend)
+        if len(pend) == 1:
+            pend[0][0].add_(pend[0][1])
+        elif pend:
+            by_dev = {}
+            for t, v in pend:
+                by_dev.setdefault((t.device, v.shape == t.shape), []).append((t, v))
+            for (_, same), pairs in by_dev.items():
+                if same:
+                    torch._foreach_add_([t for t, _ in pairs], [v for _, v in pairs])       # one launch for all meters of this call
+                else:
+                    for t, v in pairs:
+                        t.add_(v)
 
     def __getattr__(self, attr):
         if attr in self.meters:

@@ -44,7 +44,7 @@ class _LogitLossFn(torch.autograd.Function):
                                            z_t=None if z_t is None else z_t.contiguous().float(), tau=tau, w_base=w_base, w_kd=w_kd)
         ctx.dz, ctx.dz_kd = dz, dz_kd
         ctx.mark_non_differentiable(losses)
-        return w_base * losses[0] + w_kd * losses[1], losses      # losses = (base, distill), unweighted
+        return losses[2], losses      # losses = (base, distill, w_base * base + w_kd * distill, w_base * base, w_kd * distill)
 
     @staticmethod
     def backward(ctx, g, _):
@@ -417,7 +417,7 @@ class DistillationLoss(nn.Module):
         if isinstance(crit, (SoftTargetCrossEntropy, LabelSmoothingCrossEntropy)):
             sm = crit.smoothing if isinstance(crit, LabelSmoothingCrossEntropy) else 0.0
             loss, parts = _LogitLossFn.apply(outputs, z_kd, _prep_target(labels, outputs.device), z_t, kd_mode, sm, self.tau, w_base, w_kd)
-            self.last_base_loss, self.last_distill_loss = parts[0] * w_base, parts[1] * w_kd
+            self.last_base_loss, self.last_distill_loss = parts[3], parts[4]
             return loss
         loss = crit(outputs, labels) * w_base          # foreign criterion: torch autograd handles it
         self.last_base_loss, self.last_distill_loss = loss.detach(), torch.zeros_like(loss.detach())

@@ -305,14 +305,15 @@ def add_rows(x, y, *, ymap=IDENT, accumulate=True, M=None):
 
 
 def logit_loss(z, target, *, smoothing=0.1, kd_mode=0, z_kd=None, z_t=None, tau=1.0, w_base=1.0, w_kd=0.0):
-    """-> (losses f32 [2] = (base, distill), dz, dz_kd | None).  target: f32 [B, C] soft targets or int64 [B] labels."""
+    """-> (losses f32 [5] = (base, distill, w_base * base + w_kd * distill, w_base * base, w_kd * distill), dz, dz_kd | None).
+    target: f32 [B, C] soft targets or int64 [B] labels."""
     assert z.dtype == F32 and z.is_contiguous()
     B, Cc = z.shape
     soft = target if target.dtype == F32 else None
     labels = target if target.dtype == torch.int64 else None
     if soft is None and labels is None:
         raise TypeError("target must be f32 soft targets or int64 labels")
-    losses = torch.zeros(2, device=z.device, dtype=F32)
+    losses = torch.zeros(5, device=z.device, dtype=F32)
     dz = torch.empty_like(z)
     dz_kd = torch.empty_like(z) if kd_mode else None
     if kd_mode:
@@ -320,6 +321,17 @@ def logit_loss(z, target, *, smoothing=0.1, kd_mode=0, z_kd=None, z_t=None, tau=
     check(lib().dkd_logit_loss(ptr(z), ptr(soft), ptr(labels), smoothing, kd_mode, ptr(z_kd), ptr(z_t), tau, w_base, w_kd,
                                ptr(losses), ptr(dz), ptr(dz_kd), B, Cc, stream()), "logit_loss")
     return losses, dz, dz_kd
+
+
+def topk_correct(z, labels, ks):
+    """z f32 [B, C], labels int64 [B] -> f32 [len(ks)]: percentage of rows whose label is among the top ks[i] logits."""
+    import ctypes
+    assert z.dtype == F32 and z.is_contiguous() and labels.dtype == torch.int64 and labels.is_contiguous() and 1 <= len(ks) <= 4
+    out = torch.zeros(len(ks), device=z.device, dtype=F32)
+    arr = (ctypes.c_int32 * len(ks))(*[int(k) for k in ks])
+    check(lib().dkd_topk_correct(ptr(z), ptr(labels), z.shape[0], z.shape[1], ctypes.cast(arr, ctypes.c_void_p), len(ks), ptr(out),
+                                 stream()), "topk_correct")
+    return out
 
 
 def mse_loss(a, t, loss, w_over_denom, *, M=None, tmap=IDENT, mask=None, grad=True, grad_f32=False, grad_out=None):

@@ -8,6 +8,14 @@ import torch
 
 def accuracy(output, target, topk=(1,)):
     """top-k accuracy in percent as 0-dim tensors (timm.utils.accuracy)."""
+    if output.is_cuda and output.dim() == 2 and target.dim() == 1 and 1 <= len(topk) <= 4 and target.dtype in (torch.int64, torch.int32):
+        # device logits: one libdkd launch (rank of the label's logit per row) instead of topk + sort + compare + reductions
+        from . import ops
+        z = output.detach()
+        if z.dtype != torch.float32 or not z.is_contiguous():
+            z = z.float().contiguous()
+        acc = ops.topk_correct(z, target.to(torch.int64).contiguous(), [min(k, output.size(1)) for k in topk])
+        return [acc[i] for i in range(len(topk))]
     maxk = min(max(topk), output.size(1))
     batch = target.size(0)
     _, pred = output.topk(maxk, 1, True, True)

@@ -222,11 +222,16 @@ int dkd_mixup_targets(const int64_t* labels, float* out, int32_t B, int32_t C, f
 /* ema <- decay * ema + (1 - decay) * p over a flat parameter buffer (timm ModelEma [3P], tools/engine.py:68-69). */
 int dkd_ema_update(float* ema, const float* p, int64_t n, float decay, void* stream);
 
+/* top-k accuracy in percent (timm.utils.accuracy [3P], called at tools/engine.py:54-56): out f32 [nk] += 100 / B for every row of
+ * z f32 [B, C] whose label's logit is beaten by fewer than ks[i] others (ties go to the lower index).  nk <= 4; caller zeroes out. */
+int dkd_topk_correct(const float* z, const int64_t* labels, int32_t B, int32_t C, const int32_t* ks, int32_t nk, float* out, void* stream);
+
 /* ---------------------------------------------------------------- losses (fused value + gradient) */
 /* Base criterion + optional logit distillation in one pass (model/loss.py:35,57-67,241; timm SoftTargetCrossEntropy /
  * LabelSmoothingCrossEntropy [3P]).  z f32 [B, C] student logits; exactly one of soft_target f32 [B, C] / labels i64 [B].
  * kd_mode 0 none, 1 soft (KL, tau, /(B*C)), 2 hard (CE vs argmax teacher); z_kd/z_t f32 [B, C].
- * Outputs: losses[0] = base, losses[1] = distill (sums accumulated atomically: caller zeroes losses first),
+ * Outputs: losses f32 [5]: [0] = base, [1] = distill, [2] = w_base * base + w_kd * distill (what model/loss.py:241 returns),
+ * [3] = w_base * base, [4] = w_kd * distill (sums accumulated atomically: caller zeroes all five first),
  * dz = w_base * dbase/dz, dz_kd = w_kd * ddistill/dz_kd   (f32 [B, C]). */
 int dkd_logit_loss(const float* z, const float* soft_target, const int64_t* labels, float smoothing, int32_t kd_mode,
                    const float* z_kd, const float* z_t, float tau, float w_base, float w_kd, float* losses, float* dz,

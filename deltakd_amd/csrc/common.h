@@ -146,6 +146,8 @@ static inline hipStream_t as_stream(void* s) { return (hipStream_t)s; }
 // norm.hip: dgamma[c] += sum_b part[b][c], dbeta[c] += sum_b part[b][D + c] over nblk partial rows of 2 D floats (the second launch of
 // the LayerNorm backward; also closes the fused dgrad + LayerNorm-backward GEMM of gemm.hip)
 int dkd_ln_bwd_reduce(const float* part, int nblk, float* dgamma, float* dbeta, int D, void* stream);
+void dkd_ln_capture_begin(DkdLnReduce* items, int cap);      // dkd_ln_bwd_reduce records into `items` instead of launching ...
+int dkd_ln_capture_end();                                    // ... until here; returns how many were recorded
 
 // Launch probe of bench.py (api.hip): while dkd_probe_begin() .. dkd_probe_end*() is active, the scope brackets the launches made
 // inside it with HIP events recorded on THEIR stream and files them under `sym` with their algorithmic FLOPs / bytes.

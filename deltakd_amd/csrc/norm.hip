@@ -183,8 +183,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
 // sums its chunk of partial rows (4 waves, unrolled by 4 for loads in flight) and adds ONE value per column atomically -- 32
 // adds per address instead of one per ln_bwd block.
 constexpr int LNR_CHUNKS = 32;
-__global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restrict__ part, int nblk, float* __restrict__ dgamma,
-                                                            float* __restrict__ dbeta, int D) {
+__device__ __forceinline__ void ln_bwd_reduce_body(const float* __restrict__ part, int nblk, float* __restrict__ dgamma,
+                                                   float* __restrict__ dbeta, int D) {
   __shared__ float red[4][64];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + lane;          // column in [0, 2 D)
@@ -207,12 +207,53 @@ __global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restr
     atomicAdd(c < D ? &dgamma[c] : &dbeta[c - D], t);
   }
 }
+__global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restrict__ part, int nblk, float* __restrict__ dgamma,
+                                                            float* __restrict__ dbeta, int D) {
+  ln_bwd_reduce_body(part, nblk, dgamma, dbeta, D);
+}
 
 }  // namespace
 
+// While a capture list is installed (dkd_block_bwd with DkdBlockGrads.ln_defer), reductions are recorded instead of launched: the
+// caller runs them later, several blocks' worth in one launch (dkd_ln_bwd_reduce_group).
+static thread_local DkdLnReduce* ln_capture = nullptr;
+static thread_local int ln_capture_n = 0, ln_capture_cap = 0;
+void dkd_ln_capture_begin(DkdLnReduce* items, int cap) { ln_capture = items; ln_capture_n = 0; ln_capture_cap = cap; }
+int dkd_ln_capture_end() { const int n = ln_capture_n; ln_capture = nullptr; ln_capture_n = ln_capture_cap = 0; return n; }
+
 int dkd_ln_bwd_reduce(const float* part, int nblk, float* dgamma, float* dbeta, int D, void* stream) {
+  if (ln_capture && ln_capture_n < ln_capture_cap) {
+    DkdLnReduce& it = ln_capture[ln_capture_n++];
+    it.part = part; it.nblk = nblk; it.D = D; it.dgamma = dgamma; it.dbeta = dbeta;
+    return DKD_OK;
+  }
   hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3(cdiv(2 * D, 64), LNR_CHUNKS), dim3(256), 0, as_stream(stream), part, nblk, dgamma, dbeta, D);
   DKD_CHECK_LAUNCH("layernorm_bwd_reduce");
+  return DKD_OK;
+}
+
+namespace {
+constexpr int LNR_GROUP_MAX = 12;
+struct LnReduceGroup { DkdLnReduce it[LNR_GROUP_MAX]; };
+__global__ __launch_bounds__(256) void ln_bwd_reduce_group_kernel(const LnReduceGroup grp) {
+  const DkdLnReduce& q = grp.it[blockIdx.z];
+  if ((int)blockIdx.x * 64 >= 2 * q.D) return;
+  ln_bwd_reduce_body(q.part, q.nblk, q.dgamma, q.dbeta, q.D);
+}
+}  // namespace
+
+extern "C" int dkd_ln_bwd_reduce_group(const DkdLnReduce* items, int32_t n, void* stream) {
+  DKD_CHECK_ARG(items && n > 0 && n <= LNR_GROUP_MAX, "ln_bwd_reduce_group: need 1..%d reductions (n=%d)", LNR_GROUP_MAX, n);
+  LnReduceGroup grp;
+  int dmax = 0;
+  for (int i = 0; i < n; ++i) {
+    DKD_CHECK_ARG(items[i].part && items[i].dgamma && items[i].dbeta && items[i].nblk > 0 && items[i].D > 0, "ln_bwd_reduce_group: bad item %d", i);
+    grp.it[i] = items[i];
+    if (items[i].D > dmax) dmax = items[i].D;
+  }
+  DkdProbeScope probe(3, 0.0, 0.0, as_stream(stream));      // part of the student block backward's time (FLOPs / bytes counted there)
+  hipLaunchKernelGGL(ln_bwd_reduce_group_kernel, dim3(cdiv(2 * dmax, 64), LNR_CHUNKS, n), dim3(256), 0, as_stream(stream), grp);
+  DKD_CHECK_LAUNCH("layernorm_bwd_reduce_group");
   return DKD_OK;
 }
 

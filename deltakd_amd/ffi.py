@@ -63,7 +63,11 @@ class Block(C.Structure):
 class BlockGrads(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("g", "gtap", "d_ln1_w", "d_ln1_b", "d_ln2_w", "d_ln2_b", "d_qkv_w", "d_qkv_b",
                                           "d_proj_w", "d_proj_b", "d_fc1_w", "d_fc1_b", "d_fc2_w", "d_fc2_b", "dF", "dH", "dqkv", "dT",
-                                          "ln_ws", "dF2")] + [("defer_wgrad", C.c_int32)]
+                                          "ln_ws", "dF2", "ln_ws2", "ln_defer")] + [("defer_wgrad", C.c_int32)]
+
+
+class LnReduce(C.Structure):
+    _fields_ = [("part", C.c_void_p), ("nblk", C.c_int32), ("D", C.c_int32), ("dgamma", C.c_void_p), ("dbeta", C.c_void_p)]
 
 
 _lib = None
@@ -78,6 +82,7 @@ _SIGS = {
                               C.c_int32, RowMap, RowMap, C.c_void_p, C.c_void_p]),
     "dkd_gemm_tn_group": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
     "dkd_block_wgrad_group": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
+    "dkd_ln_bwd_reduce_group": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
     "dkd_conv3x3_wgrad": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "dkd_gram": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, RowMap, C.c_void_p]),
     "dkd_attn_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),

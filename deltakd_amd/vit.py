@@ -424,6 +424,10 @@ def flush_wgrads(model):
             q.amap = q.bmap = IDENT
             k += 1
     ffi.check(ffi.lib().dkd_block_wgrad_group(ffi.C.cast(probs, ffi.C.c_void_p), n, ffi.stream()), "block wgrad group")
+    red = [it for entry in pend for it in entry["ln"] if it.part]       # the LayerNorm dgamma / dbeta reductions of the same blocks
+    for lo in range(0, len(red), 12):
+        arr = (ffi.LnReduce * len(red[lo:lo + 12]))(*red[lo:lo + 12])
+        ffi.check(ffi.lib().dkd_ln_bwd_reduce_group(ffi.C.cast(arr, ffi.C.c_void_p), len(arr), ffi.stream()), "ln reduce group")
     hook = getattr(model, "_grad_ready_hook", None)             # data parallel: these blocks' gradients are final now
     if hook is not None:
         for entry in pend:
@@ -454,6 +458,10 @@ def _block_backward(g, gtap, model, blk: Block, saved, idx=None):
     gr.g, gr.gtap = g.data_ptr(), ffi.ptr(gtap)
     defer = side is not None or (group > 1 and bool(gr.dF2))
     gr.defer_wgrad = 1 if defer else 0
+    ln_items = None
+    if defer and side is None and not os.environ.get("DKD_NO_LN_REDUCE_GROUP"):
+        ln_items = (ffi.LnReduce * 2)()
+        gr.ln_defer = ffi.C.cast(ln_items, ffi.C.c_void_p)
     a, m = blk.attn, blk.mlp
     gr.d_ln1_w, gr.d_ln1_b = ensure_grad(blk.norm1.weight).data_ptr(), ensure_grad(blk.norm1.bias).data_ptr()
     gr.d_ln2_w, gr.d_ln2_b = ensure_grad(blk.norm2.weight).data_ptr(), ensure_grad(blk.norm2.bias).data_ptr()
@@ -469,7 +477,7 @@ def _block_backward(g, gtap, model, blk: Block, saved, idx=None):
                 (gr.dF2, bs.o, gr.d_proj_w, gr.d_proj_b, D, D), (gr.dqkv, bs.y1, gr.d_qkv_w, gr.d_qkv_b, 3 * D, D))
     if side is None:
         # (slab16 / ln1 hold h, y2, o, y1; kept alive here until the flush has been enqueued -- same stream, so that is enough)
-        pend.append({"M": M, "problems": problems, "idx": idx, "keep": (slab16, ln1, ws, bs)})
+        pend.append({"M": M, "problems": problems, "idx": idx, "keep": (slab16, ln1, ws, bs), "ln": ln_items if ln_items is not None else ()})
         return g, True
     probs = (ffi.TnProblem * 4)()
     for q, (pa, pb, pc, pcs, n1, n2) in zip(probs, problems):

@@ -324,6 +324,17 @@ typedef struct {
   float *next_mean1, *next_rstd1;
 } DkdBlock;
 
+/* A deferred LayerNorm parameter-gradient reduction: dgamma[c] += sum_b part[b][c], dbeta[c] += sum_b part[b][D + c] over nblk
+ * partial rows of 2 * D floats (what the LayerNorm-backward kernels leave in their scratch). */
+typedef struct DkdLnReduce {
+  const float* part;
+  int32_t nblk, D;
+  float* dgamma;
+  float* dbeta;
+} DkdLnReduce;
+/* Up to 12 of them in one launch. */
+int dkd_ln_bwd_reduce_group(const DkdLnReduce* items, int32_t n, void* stream);
+
 typedef struct {
   float* g;                          /* in: d loss / d x2 (f32 [M, D]); out: d loss / d x (in place)                     */
   const void* gtap;                  /* bf16 [M, D] gradient of the tap or NULL                                          */
@@ -332,6 +343,11 @@ typedef struct {
   void* dT;                          /* bf16 workspace [M, D]                                                            */
   float* ln_ws;                      /* f32 scratch, 2 * D * ceil(M / 64) floats, for the LayerNorm backward partial sums; or NULL */
   void* dF2;                         /* second bf16 [M, D] workspace or NULL: with it all four weight gradients are one launch   */
+  float* ln_ws2;                     /* second LayerNorm scratch (same size as ln_ws), needed with ln_defer                       */
+  DkdLnReduce* ln_defer;             /* array of 2 or NULL.  Non-NULL: the two dgamma / dbeta reductions of the block's LayerNorms are
+                                        NOT launched; dkd_block_bwd describes them here ([0] norm2 over ln_ws, [1] norm1 over ln_ws2)
+                                        and the caller runs dkd_ln_bwd_reduce_group over the blocks it has collected (the student
+                                        flushes them with its deferred weight gradients: 2 launches per step instead of 24)       */
   int32_t defer_wgrad;               /* 1 (needs dF2): do NOT launch the four weight gradients; the caller issues them itself
                                         (dkd_block_wgrad_group over dF/h, dH/y2, dF2/o, dqkv/y1, for one block or for several
                                         whose workspaces it keeps alive until then) */

@@ -180,15 +180,15 @@ def test_c_abi_library_exports_every_declared_symbol():
     al = lambda n: (n + 255) // 256 * 256
     assert handle.dkd_layernorm_bwd_workspace_bytes(M, D) == al(2 * D * ((M + 63) // 64) * 4)
     assert handle.dkd_block_bwd_workspace_bytes(256, 197, D, Hd) == (3 * al(M * D * 2) + al(M * Hd * 2) + al(M * 3 * D * 2)
-                                                                      + handle.dkd_layernorm_bwd_workspace_bytes(M, D))
+                                                                      + 2 * handle.dkd_layernorm_bwd_workspace_bytes(M, D))
     b16, f32 = ffi.C.c_int64(), ffi.C.c_int64()
     tot = handle.dkd_block_fwd_workspace_bytes(256, 197, D, 3, Hd, 1, 1, ffi.C.byref(b16), ffi.C.byref(f32))
     assert tot == b16.value + f32.value and b16.value == 4 * al(M * D * 2) + al(M * 3 * D * 2) + 2 * al(M * Hd * 2)
     assert f32.value == 2 * al(M * D * 4) + 4 * al(M * 4) + al(256 * 3 * 197 * 4)
     gr = ffi.BlockGrads()
     assert handle.dkd_block_bwd_workspace_carve(0x10000, 256, 197, D, Hd, ffi.C.byref(gr)) == 0      # pointer arithmetic only
-    assert gr.dF == 0x10000 and gr.dT == gr.dF + al(M * D * 2) and gr.dF2 + al(M * D * 2) - 0x10000 == \
-        handle.dkd_block_bwd_workspace_bytes(256, 197, D, Hd)
+    assert gr.dF == 0x10000 and gr.dT == gr.dF + al(M * D * 2) and gr.ln_ws2 == gr.dF2 + al(M * D * 2) and \
+        gr.ln_ws2 + handle.dkd_layernorm_bwd_workspace_bytes(M, D) - 0x10000 == handle.dkd_block_bwd_workspace_bytes(256, 197, D, Hd)
 
 
 def test_checkpoint_helpers_follow_the_reference_wire_format(tmp_path):

@@ -1427,9 +1427,19 @@ __global__ __launch_bounds__(256, 2) void gemm_tn192_kernel(const bf16_t* __rest
 //  * rows past M and columns past N1 / N2 are sourced from a 16-byte page of zeros.
 //  * the fused bias gradient (column sums of dY) is one more MFMA per row tile against a fragment of ones.
 
-constexpr int TND_A_ST = 32 * 256, TND_UNIT = TND_A_ST + 32 * 384, TND_RING = 4;
-constexpr int TND_SMEM = TND_RING * TND_UNIT;                                    // 80 KiB; the epilogue reuses 49 KiB of it
-static_assert(TND_SMEM >= 64 * T192_CS * 4, "epilogue staging must fit");
+// WR wave rows of 64 tile rows each: WR = 2 is the 128 x 192 tile (4 waves, 80 KiB ring, two workgroups per CU), WR = 4 the 256 x 192
+// tile (8 waves, 112 KiB, one per CU): per 32-row unit it moves 28 KiB for twice the FLOPs of the small tile's 20 KiB -- the kernel
+// runs at the rate of its LDS-DMA stream, and in a grouped launch the tiles of several gradients supply the parallelism.
+template <int WR> struct TndCfg {
+  static constexpr int AW = 64 * WR;                 // A columns (tile rows of C) per workgroup
+  static constexpr int A_ROWB = AW * 2;              // bytes per A row in LDS
+  static constexpr int A_ST = 32 * A_ROWB;           // one unit of A
+  static constexpr int UNIT = A_ST + 32 * 384;
+  static constexpr int RING = WR == 2 ? 4 : 5;       // units resident (one multiplied, the rest in flight): 80 KiB / 140 KiB
+  static constexpr int SMEM = RING * UNIT;
+  static constexpr int WAVES = 2 * WR;
+};
+static_assert(TndCfg<2>::SMEM >= 64 * T192_CS * 4, "epilogue staging must fit");
 
 // One problem of the kernel, in kernel-operand order (the host has already swapped the operands when the wide one is A).
 struct TnProb {
@@ -1442,40 +1452,49 @@ struct TnProb {
   int units_per_split, tiles1, swap, n_blocks;     // n_blocks: tiles1 * splits rounded up to a multiple of 8
 };
 
-// `bid` / `nblk`: this block's index inside its problem and the problem's block count (both in launch order, so bid % 8 is the XCD)
+// `bid` / `nblk`: this block's index inside its problem and the problem's block count (both in launch order, so bid % 8 is the XCD).
+// PB: B pieces this wave issues per unit (3 with 4 waves; with 8 waves the 12 pieces are 2 each for waves 0-3, 1 each for waves 4-7 --
+// the counted waits need the per-wave piece count at compile time, so the two halves run two instantiations).
+template <int WR, int PB>
 __device__ __forceinline__ void tn192d_body(char* smem, const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, float* C, int M,
                                             int N1, int N2, int lda, int ldb, int ldc, const DkdRowMap& amap, const DkdRowMap& bmap,
                                             int units_per_split, float* __restrict__ colsum, int tiles1, const bool SWAP, int bid,
-                                            int nblk) {
-  constexpr int A_ST = TND_A_ST, UNIT = TND_UNIT, RING = TND_RING, PIECES = 5;   // per wave: 2 pieces of A, 3 of B
+                                            int nblk, int rot = 0) {
+  using Cfg = TndCfg<WR>;
+  constexpr int A_ST = Cfg::A_ST, UNIT = Cfg::UNIT, RING = Cfg::RING, PIECES = 2 + PB, A_ROWB = Cfg::A_ROWB, AW = Cfg::AW;
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = w >> 1, wc = w & 1;
   // 1-D grid, XCD-aware: each XCD gets a contiguous run of (split, tile) ids with the tiles of a split adjacent, so the blocks
   // that stream the same rows of the 192-wide operand run on the same XCD at the same time and share them through its L2
   // (dealt round-robin, every XCD fetched those rows again: twice the HBM/fabric traffic for a 768 x 192 gradient)
-  const int L = xcd_remap(bid, nblk);
+  // (rot: a group launch pads every problem's block range to a multiple of 8 and the padding sits at the END of the remapped list, i.e.
+  // on the last XCDs; rotating the XCD labels by the problem's index spreads the idle slots over all eight -- with one 8-wave workgroup
+  // per CU and 12 real blocks of 16, two XCDs had no work at all and the others ran two rounds)
+  const int L = xcd_remap((bid & ~7) | ((bid + rot) & 7), nblk);
   const int tile = L % tiles1, split = L / tiles1;
-  const int n1_0 = tile * 128;
+  const int n1_0 = tile * AW;
   const int U_all = (M + 31) / 32;
   const int u_begin = split * units_per_split;
   const int u_end = min(U_all, u_begin + units_per_split);
   if (u_begin >= u_end) return;
   const int n_units = u_end - u_begin;
 
-  // ---- per-lane DMA sources.  piece c < 2: A piece w*2 + c (4 rows x 256 B each); else B piece w*3 + (c-2) (1 KiB of 384-B rows)
+  // ---- per-lane DMA sources.  piece c < 2: A piece w*2 + c (1 KiB of A_ROWB-byte rows); else one of the 12 B pieces (1 KiB of 384-B rows)
+  const int b_first = WR == 2 ? w * 3 : (w < 4 ? w * 2 : 8 + (w - 4));
   int prow[PIECES], pcol[PIECES];        // row inside the unit, source column (elements); pcol < 0: zero page
 #pragma unroll
   for (int c = 0; c < PIECES; ++c) {
     if (c < 2) {
       const int off = (w * 2 + c) * 1024 + lane * 16;
-      const int row = off >> 8, p = (off >> 4) & 15;
-      const int g = (p >> 1) ^ (row & 7);
+      const int row = off / A_ROWB, p = (off % A_ROWB) >> 4;       // 16-byte chunk inside the row
+      const int G = p >> 1;                                        // 32-byte granule
+      const int g = (G & ~7) | ((G & 7) ^ (row & 7));
       const int col = n1_0 + g * 16 + (p & 1) * 8;
       prow[c] = row;
       pcol[c] = col < N1 ? col : -1;
     } else {
-      const int off = (w * 3 + (c - 2)) * 1024 + lane * 16;
+      const int off = (b_first + (c - 2)) * 1024 + lane * 16;
       const int row = off / 384, cb = off % 384;
       const int G = cb >> 5;
       const int g = (G & ~3) | ((G & 3) ^ ((row >> 1) & 3));
@@ -1507,7 +1526,7 @@ __device__ __forceinline__ void tn192d_body(char* smem, const bf16_t* __restrict
     const bf16_t* base = c < 2 ? A : B;
     const int ld = c < 2 ? lda : ldb;
     const bf16_t* src = (pcol[c] >= 0 && m < M) ? base + srow * ld + pcol[c] : zero;
-    const uint32_t dst = (uint32_t)(uintptr_t)LDS_PTR(smem) + slot * UNIT + (c < 2 ? (w * 2 + c) * 1024 : A_ST + (w * 3 + (c - 2)) * 1024);
+    const uint32_t dst = (uint32_t)(uintptr_t)LDS_PTR(smem) + slot * UNIT + (c < 2 ? (w * 2 + c) * 1024 : A_ST + (b_first + (c - 2)) * 1024);
 #pragma clang diagnostic push
 #pragma clang diagnostic ignored "-Winline-asm"
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(dst), "v"(src) : "memory", "m0");
@@ -1546,7 +1565,10 @@ __device__ __forceinline__ void tn192d_body(char* smem, const bf16_t* __restrict
   const int fcol = 8 * (i16 & 3);
   int a_off[4], b_off[6];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) a_off[i] = frow * 256 + (((wr * 4 + i) ^ (frow & 7)) * 32) + fcol;
+  for (int i = 0; i < 4; ++i) {
+    const int G = wr * 4 + i;
+    a_off[i] = frow * A_ROWB + (((G & ~7) | ((G & 7) ^ (frow & 7))) * 32) + fcol;
+  }
 #pragma unroll
   for (int j = 0; j < 6; ++j) {
     const int g = wc * 6 + j;
@@ -1574,7 +1596,7 @@ __device__ __forceinline__ void tn192d_body(char* smem, const bf16_t* __restrict
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)LDS_PTR(base + a_off[i]));
-      const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)LDS_PTR(base + a_off[i] + 16 * 256));
+      const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)LDS_PTR(base + a_off[i] + 16 * A_ROWB));
       a[i] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
     }
 #pragma unroll
@@ -1619,7 +1641,7 @@ __device__ __forceinline__ void tn192d_body(char* smem, const bf16_t* __restrict
     }
   }
   float* cs = (float*)smem;
-  for (int h = 0; h < 2; ++h) {
+  for (int h = 0; h < WR; ++h) {
     __syncthreads();
     if (wr == h) {
 #pragma unroll
@@ -1630,7 +1652,7 @@ __device__ __forceinline__ void tn192d_body(char* smem, const bf16_t* __restrict
           for (int r = 0; r < 4; ++r) cs[(i * 16 + fg * 4 + r) * T192_CS + wc * 96 + j * 16 + i16] = acc[i][j][r];
     }
     __syncthreads();
-    for (int idx = tid; idx < 64 * 192; idx += 256) {
+    for (int idx = tid; idx < 64 * 192; idx += 64 * Cfg::WAVES) {
       int rl, cl;
       if (SWAP) { cl = idx >> 6; rl = idx & 63; }            // lanes run along n1 (contiguous in the caller's transposed C)
       else { rl = idx / 192; cl = idx % 192; }
@@ -1647,20 +1669,21 @@ template <bool SWAP>
 __global__ __launch_bounds__(256, 2) void gemm_tn192d_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, float* C, int M,
                                                              int N1, int N2, int lda, int ldb, int ldc, DkdRowMap amap, DkdRowMap bmap,
                                                              int units_per_split, float* __restrict__ colsum, int tiles1) {
-  __shared__ __attribute__((aligned(16))) char smem[TND_SMEM];
-  tn192d_body(smem, A, B, C, M, N1, N2, lda, ldb, ldc, amap, bmap, units_per_split, colsum, tiles1, SWAP, blockIdx.x, gridDim.x);
+  __shared__ __attribute__((aligned(16))) char smem[TndCfg<2>::SMEM];
+  tn192d_body<2, 3>(smem, A, B, C, M, N1, N2, lda, ldb, ldc, amap, bmap, units_per_split, colsum, tiles1, SWAP, blockIdx.x, gridDim.x);
 }
 
-// Up to four independent weight gradients in ONE launch (the two of an MLP, the two of an attention branch): each alone is ~1.5
-// blocks per CU that all start and end together, so its ring fill and its atomic epilogue overlap nothing; side by side the blocks
-// of one problem fill in while another's drain.  Block ranges are padded to multiples of 8 so blockIdx % 8 stays the XCD.
+// Up to 24 independent weight gradients in ONE launch (the two of an MLP, the four of a transformer block, those of several blocks):
+// each alone is ~1.5 blocks per CU that all start and end together, so its ring fill and its atomic epilogue overlap nothing; side by
+// side the blocks of one problem fill in while another's drain.  Block ranges are padded to multiples of 8 so blockIdx % 8 stays the XCD.
 constexpr int TN_GROUP_MAX = 24;        // 24 x 96 B of kernel arguments (the limit is 4 KiB)
 struct TnGroup {
   TnProb p[TN_GROUP_MAX];
   int n;
 };
-__global__ __launch_bounds__(256, 2) void gemm_tn192g_kernel(const TnGroup grp) {
-  __shared__ __attribute__((aligned(16))) char smem[TND_SMEM];
+template <int WR>
+__global__ __launch_bounds__(128 * WR, WR == 2 ? 2 : 1) void gemm_tn192g_kernel(const TnGroup grp) {
+  __shared__ __attribute__((aligned(16))) char smem[TndCfg<WR>::SMEM];
   int bid = blockIdx.x, k = 0;
   while (k + 1 < grp.n && bid >= grp.p[k].n_blocks) {
     bid -= grp.p[k].n_blocks;
@@ -1668,8 +1691,17 @@ __global__ __launch_bounds__(256, 2) void gemm_tn192g_kernel(const TnGroup grp) 
   }
   const TnProb& q = grp.p[k];
   if (bid >= q.n_blocks) return;
-  tn192d_body(smem, q.A, q.B, q.C, q.M, q.N1, q.N2, q.lda, q.ldb, q.ldc, q.amap, q.bmap, q.units_per_split, q.colsum, q.tiles1,
-              q.swap != 0, bid, q.n_blocks);
+  if constexpr (WR == 2) {
+    tn192d_body<2, 3>(smem, q.A, q.B, q.C, q.M, q.N1, q.N2, q.lda, q.ldb, q.ldc, q.amap, q.bmap, q.units_per_split, q.colsum, q.tiles1,
+                      q.swap != 0, bid, q.n_blocks, k);
+  } else {
+    if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) < 4)
+      tn192d_body<4, 2>(smem, q.A, q.B, q.C, q.M, q.N1, q.N2, q.lda, q.ldb, q.ldc, q.amap, q.bmap, q.units_per_split, q.colsum, q.tiles1,
+                        q.swap != 0, bid, q.n_blocks, k);
+    else
+      tn192d_body<4, 1>(smem, q.A, q.B, q.C, q.M, q.N1, q.N2, q.lda, q.ldb, q.ldc, q.amap, q.bmap, q.units_per_split, q.colsum, q.tiles1,
+                        q.swap != 0, bid, q.n_blocks, k);
+  }
 }
 
 }  // namespace
@@ -1855,12 +1887,12 @@ extern "C" int dkd_gemm_nt(const DkdGemm* gp, void* stream) {
 
 namespace {
 // kernel-order description of one weight gradient for the LDS-DMA ring kernel, or false when it must take the other kernels
-bool tn192d_plan(const DkdTnProblem& q, TnProb* out, int min_tiles, int target_blocks = 384) {
+bool tn192d_plan(const DkdTnProblem& q, TnProb* out, int min_tiles, int target_blocks = 384, int aw = 128) {
   const bool wide_b = q.N2 > 128 && q.N2 <= 192;
   const bool wide_a = !wide_b && q.N1 > 128 && q.N1 <= 192 && q.N2 > 192;
   if (!(wide_b || wide_a) || q.N1 % 8 || q.N2 % 8 || q.M < 32 * 16) return false;
   if ((q.lda % 8) || (q.ldb % 8) || ((uintptr_t)q.A & 15) || ((uintptr_t)q.B & 15)) return false;
-  const int t1 = cdiv(wide_b ? q.N1 : q.N2, 128);
+  const int t1 = cdiv(wide_b ? q.N1 : q.N2, aw);
   if (t1 < min_tiles) return false;
   const int U = cdiv(q.M, 32);
   int sp = cdiv(target_blocks, t1);    // alone: 1.5 blocks per CU -- fewer partial tiles to add atomically than at 2 (measured 256..768)
@@ -1915,12 +1947,12 @@ extern "C" int dkd_gemm_nt_lnbwd(const void* A, const void* W, int32_t M, int32_
 
 namespace {
 // Tile columns the ring kernel would cut problem q into, or 0 when it does not take the shape (same test as tn192d_plan).
-int tn192d_tiles(const DkdTnProblem& q) {
+int tn192d_tiles(const DkdTnProblem& q, int aw) {
   const bool wide_b = q.N2 > 128 && q.N2 <= 192;
   const bool wide_a = !wide_b && q.N1 > 128 && q.N1 <= 192 && q.N2 > 192;
   if (!(wide_b || wide_a) || q.N1 % 8 || q.N2 % 8 || q.M < 32 * 16) return 0;
   if ((q.lda % 8) || (q.ldb % 8) || ((uintptr_t)q.A & 15) || ((uintptr_t)q.B & 15)) return 0;
-  return cdiv(wide_b ? q.N1 : q.N2, 128);
+  return cdiv(wide_b ? q.N1 : q.N2, aw);
 }
 
 int tn_group_launch(const DkdTnProblem* probs, int n, void* stream) {
@@ -1931,8 +1963,15 @@ int tn_group_launch(const DkdTnProblem* probs, int n, void* stream) {
   // themselves supply the parallelism: 114 tiles -> 4 splits, i.e. a quarter of the atomically added partial tiles per gradient.
   static const int slots_env = getenv("DKD_TN_GROUP_SLOTS") ? atoi(getenv("DKD_TN_GROUP_SLOTS")) : 0;       // (dev: A/B)
   static const int blocks_env = getenv("DKD_TN_GROUP_BLOCKS") ? atoi(getenv("DKD_TN_GROUP_BLOCKS")) : 0;    // (dev: round 2's rule)
+  // DKD_TN_GROUP_WIDE=1 (dev, A/B): 256 x 192 tiles, one 8-wave workgroup per CU -- 28 KiB of LDS-DMA per unit for twice the FLOPs of
+  // the 128-row tile's 20 KiB.  Measured (tools_dev/wgrad_bench.py, six blocks = 24 problems): 560 us either way at 8 splits, 860 us at
+  // 4 (one workgroup per CU): the launch already runs at the rate a CU gathers rows that come from HBM (~24 GB/s per CU,
+  // MI355X_MICROARCH.md "Indexed rows"), which the tile shape does not change, so the 128-row tiles (two workgroups per CU) stay.
+  static const int wide_env = getenv("DKD_TN_GROUP_WIDE") ? atoi(getenv("DKD_TN_GROUP_WIDE")) : 0;
+  const bool wide = wide_env && n >= 4;
+  const int aw = wide ? 256 : 128;
   int total_tiles = 0;
-  for (int i = 0; i < n; ++i) total_tiles += tn192d_tiles(probs[i]);
+  for (int i = 0; i < n; ++i) total_tiles += tn192d_tiles(probs[i], aw);
   int splits = total_tiles > 0 ? (slots_env > 0 ? slots_env : 512) / total_tiles : 1;
   if (splits < 1) splits = 1;
   TnGroup grp;
@@ -1941,8 +1980,8 @@ int tn_group_launch(const DkdTnProblem* probs, int n, void* stream) {
   for (int i = 0; i < n; ++i) {
     const DkdTnProblem& q = probs[i];
     DKD_CHECK_ARG(q.A && q.B && q.C && q.M > 0 && q.N1 > 0 && q.N2 > 0, "gemm_tn_group: bad problem %d", i);
-    const int t1 = tn192d_tiles(q);
-    if (t1 > 0 && tn192d_plan(q, &grp.p[grp.n], 1, blocks_env > 0 ? blocks_env : t1 * splits)) {
+    const int t1 = tn192d_tiles(q, aw);
+    if (t1 > 0 && tn192d_plan(q, &grp.p[grp.n], 1, blocks_env > 0 ? blocks_env : t1 * splits, aw)) {
       total += grp.p[grp.n].n_blocks;
       ++grp.n;
     } else {                            // shapes the ring kernel does not take: launched on their own
@@ -1951,7 +1990,8 @@ int tn_group_launch(const DkdTnProblem* probs, int n, void* stream) {
     }
   }
   if (grp.n > 0) {
-    hipLaunchKernelGGL(gemm_tn192g_kernel, dim3(total), dim3(256), 0, as_stream(stream), grp);
+    if (wide) hipLaunchKernelGGL(gemm_tn192g_kernel<4>, dim3(total), dim3(512), 0, as_stream(stream), grp);
+    else hipLaunchKernelGGL(gemm_tn192g_kernel<2>, dim3(total), dim3(256), 0, as_stream(stream), grp);
     DKD_CHECK_LAUNCH("gemm_tn_group");
   }
   return DKD_OK;

@@ -373,14 +373,18 @@ class DistillationLoss(nn.Module):
         fwt = getattr(_unwrap(t), "forward_with_taps", None)
         if fwt is None:
             raise RuntimeError("teacher model has no forward_with_taps(); build it with deltakd_amd.vit.create_model")
-        logits, taps = fwt(inputs, self._TAPS.get(kind))
+        # (the teacher's logits feed soft / hard only -- model/loss.py:57-67; the feature criteria read its taps: no head launches)
+        try:
+            logits, taps = fwt(inputs, self._TAPS.get(kind), head=False)
+        except TypeError:                               # a foreign model's forward_with_taps without the keyword
+            logits, taps = fwt(inputs, self._TAPS.get(kind))
         pt = getattr(_unwrap(t), "num_prefix_tokens", 2)
         want_tgt = kind == "lrkd" and "lrkd_targets" not in self.injected
         if sizes is None:
             tgt = self.lowrank([taps[0], taps[1], taps[11]], pt, lrkd_rank) if want_tgt else None
             return logits, taps, tgt
         out, lo = [], 0
-        for z, n in zip(torch.split(logits, sizes), sizes):
+        for z, n in zip(torch.split(logits, sizes) if logits is not None else [None] * len(sizes), sizes):
             part = [None if tp is None else tp[lo:lo + n] for tp in taps]          # contiguous [n, N, D] slices of [sum, N, D]
             tgt = self.lowrank([part[0], part[1], part[11]], pt, lrkd_rank) if want_tgt else None
             out.append((z, part, tgt))

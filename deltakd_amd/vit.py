@@ -842,11 +842,12 @@ class VisionTransformer(nn.Module):
             return outs[0], outs[1]
         return (outs[0] + outs[1]) / 2
 
-    def forward_with_taps(self, img, tap_layers=None):
+    def forward_with_taps(self, img, tap_layers=None, head=True):
         """``tap_layers`` None: the model's ``tap_layers`` attribute (default None = every block, what the reference's
-        forward_with_features returns); the training loop narrows it to the blocks its criterion reads."""
+        forward_with_features returns); the training loop narrows it to the blocks its criterion reads.  ``head=False``: the logits
+        are not computed (returned as None) -- the feature-matching criteria never read the teacher's."""
         x, taps = self.forward_tokens(img, self.tap_layers if tap_layers is None else tap_layers)
-        return self.forward_head(x, img.shape[0]), taps
+        return (self.forward_head(x, img.shape[0]) if head else None), taps
 
     def forward(self, img):
         x, _ = self.forward_tokens(img, tap_layers=())

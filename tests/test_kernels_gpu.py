@@ -218,6 +218,59 @@ def test_gemm_tn_group_matches_single_launches(ops):
         close(kw["colsum"], rcs, 1e-4, f"group colsum {shp}")
 
 
+@pytest.mark.parametrize("n_blocks", [1, 3, 6])
+def test_block_wgrad_group_of_several_blocks(ops, n_blocks):
+    """dkd_block_wgrad_group with 4, 12 and 24 problems (the weight gradients of 1 / 3 / 6 student blocks: fc2, fc1, proj, qkv shapes at
+    D = 192): every tile gets the same number of M splits (26 / 8 / 4 here), each result against fp32 torch; M not a multiple of the
+    32-row unit, outputs pre-filled (the launch accumulates)."""
+    from deltakd_amd import ffi
+    from deltakd_amd.ffi import IDENT
+    M, D, Hd = 37 * 197, 192, 768
+    probs = (ffi.TnProblem * (4 * n_blocks))()
+    keep, refs = [], []
+    k = 0
+    for b in range(n_blocks):
+        for n1, n2 in ((D, Hd), (Hd, D), (D, D), (3 * D, D)):
+            a = rnd(M, n1, seed=900 + k).to(BF16)
+            bb = rnd(M, n2, seed=950 + k).to(BF16)
+            c = torch.full((n1, n2), 0.5, device=dev())
+            cs = torch.zeros(n1, device=dev())
+            keep.append((a, bb, c, cs))
+            refs.append((0.5 + a.float().t() @ bb.float(), a.float().sum(0)))
+            q = probs[k]
+            q.A, q.B, q.C, q.a_colsum, q.M, q.N1, q.N2, q.lda, q.ldb, q.ldc = a.data_ptr(), bb.data_ptr(), c.data_ptr(), cs.data_ptr(), M, n1, n2, n1, n2, n2
+            q.amap = q.bmap = IDENT
+            k += 1
+    ffi.check(ffi.lib().dkd_block_wgrad_group(ffi.C.cast(probs, ffi.C.c_void_p), 4 * n_blocks, ffi.stream()), "wgrad group")
+    for i, ((a, bb, c, cs), (ref, rcs)) in enumerate(zip(keep, refs)):
+        close(c, ref, 1e-4, f"problem {i} {tuple(c.shape)}")
+        close(cs, rcs, 1e-4, f"colsum {i}")
+    rc = ffi.lib().dkd_block_wgrad_group(ffi.C.cast(probs, ffi.C.c_void_p), 25, ffi.stream())
+    assert rc != 0 and b"1..24" in ffi.lib().dkd_last_error()
+
+
+def test_ln_bwd_reduce_group(ops):
+    """dkd_ln_bwd_reduce_group: several deferred LayerNorm dgamma / dbeta reductions (different row counts, D = 192 and 384) in one
+    launch == summing the partial rows in torch, accumulated onto what the gradients already hold."""
+    from deltakd_amd import ffi
+    items, keep = [], []
+    for i, (nblk, D) in enumerate(((256, 192), (788, 192), (17, 192), (300, 384), (1, 192))):
+        part = rnd(nblk, 2 * D, seed=400 + i)
+        dg = rnd(D, seed=420 + i)
+        db = rnd(D, seed=440 + i)
+        ref = (dg + part[:, :D].sum(0), db + part[:, D:].sum(0))
+        it = ffi.LnReduce()
+        it.part, it.nblk, it.D, it.dgamma, it.dbeta = part.data_ptr(), nblk, D, dg.data_ptr(), db.data_ptr()
+        items.append(it)
+        keep.append((part, dg, db, ref))
+    arr = (ffi.LnReduce * len(items))(*items)
+    ffi.check(ffi.lib().dkd_ln_bwd_reduce_group(ffi.C.cast(arr, ffi.C.c_void_p), len(items), ffi.stream()), "ln reduce group")
+    for part, dg, db, (rg, rb) in keep:
+        close(dg, rg, 1e-5, "dgamma")
+        close(db, rb, 1e-5, "dbeta")
+    assert ffi.lib().dkd_ln_bwd_reduce_group(ffi.C.cast(arr, ffi.C.c_void_p), 13, ffi.stream()) != 0
+
+
 def ref_attention(qkv, B, N, H):
     q, k, v = qkv.float().view(B, N, 3, H, 64).permute(2, 0, 3, 1, 4)
     s = (q @ k.transpose(-1, -2)) * 0.125

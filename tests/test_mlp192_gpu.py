@@ -220,3 +220,41 @@ def test_block_with_fused_mlp_equals_the_unfused_launch_sequence(B, tap_layers, 
     worst = max((rel_l2(g_f[n], g_u[n]), n) for n in g_u if g_u[n].norm() > 0)
     assert worst[0] < 1.5e-2, f"gradient of {worst[1]} differs by {worst[0]:.3e} (relative L2)"
     assert os.environ.get("DKD_NO_MLP_FUSION") == "1"      # (the second run really took the other path)
+
+
+@pytest.mark.parametrize("group", [2, 6])
+def test_deferred_weight_gradients_equal_the_per_block_launches(group, monkeypatch):
+    """The student defers its blocks' weight gradients and LayerNorm reductions and flushes them several blocks at a time
+    (deltakd_amd.vit.flush_wgrads: DKD_WGRAD_GROUP blocks per dkd_block_wgrad_group launch).  Every parameter gradient of a 5-block
+    D = 192 model must equal the one-block-at-a-time path (group 1: launched inside dkd_block_bwd) up to the atomics' summation order;
+    with 5 blocks and groups of 2 the last flush holds one block.  A backward pass that stops above block 0
+    (``backward(inputs=[activation after block 2])``) leaves its pending gradients to the callback queued on the autograd engine."""
+    from deltakd_amd import vit
+
+    def grads(g, partial):
+        monkeypatch.setenv("DKD_WGRAD_GROUP", str(g))
+        torch.manual_seed(3)
+        m = vit.VisionTransformer(192, 5, 3, 10, False, 0.0, img_size=64, patch_size=16).to(dev()).train()
+        img = torch.randn(6, 3, 64, 64, device=dev(), generator=torch.Generator(device=dev()).manual_seed(9))
+        B, N = 6, m.num_tokens
+        x = vit._EmbedFn.apply(m.pos_embed, m, img)
+        xs = []
+        for i in range(5):
+            x, _ = vit._BlockFn.apply(x, m, i, B, N, None, None, False)
+            xs.append(x)
+        loss = m.forward_head(x, B).float().square().mean()
+        if partial:
+            loss.backward(inputs=[xs[2]])              # the engine runs the head and blocks 4, 3 only
+        else:
+            loss.backward()
+        torch.cuda.synchronize()
+        assert not vit._rt(m).get("wgrad_pending"), "nothing may stay pending after backward()"
+        return {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}
+
+    for partial in (False, True):
+        ref = grads(1, partial)
+        got = grads(group, partial)
+        assert ref.keys() == got.keys() and "blocks.4.mlp.fc1.weight" in got and ("blocks.0.attn.qkv.weight" in got) == (not partial)
+        for n in ref:
+            err = (got[n] - ref[n]).norm().item() / (ref[n].norm().item() + 1e-20)
+            assert err <= 2e-5, (partial, n, err)

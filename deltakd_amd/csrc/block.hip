@@ -29,9 +29,13 @@ int block_fwd(const DkdBlock& b, void* st) {
     if (!b.ln1_ready) TRY(dkd_layernorm_fwd(b.x, D, ID, b.ln1_w, b.ln1_b, b.y1, b.mean1, b.rstd1, M, D, b.eps, 0, st));
     g = mk(b.y1, b.qkv_w, b.qkv, M, 3 * D, D);
   }
-  g.epi = DKD_EPI_BIAS; g.bias = b.qkv_b;
-  TRY(dkd_gemm_nt(&g, st));
-  TRY(dkd_attn_fwd(b.qkv, b.o, b.lse, b.B, b.N, b.H, st));
+  if (b.fuse_attn && !(fold & 1)) {       // qkv projection + attention in one launch: q, k, v reach the attention through registers / LDS
+    TRY(dkd_attn192_fwd(b.y1, b.qkv_w, b.qkv_b, b.qkv, b.o, b.lse, b.B, b.N, st));
+  } else {
+    g.epi = DKD_EPI_BIAS; g.bias = b.qkv_b;
+    TRY(dkd_gemm_nt(&g, st));
+    TRY(dkd_attn_fwd(b.qkv, b.o, b.lse, b.B, b.N, b.H, st));
+  }
   g = mk(b.o, b.proj_w, b.x1, M, D, D);
   g.epi = DKD_EPI_BIAS | DKD_EPI_RESID | DKD_EPI_OUT_F32; g.bias = b.proj_b;
   g.resid = b.x; g.ldr = D; g.rowscale = b.s1; g.rows_per_sample = b.N;
@@ -71,6 +75,7 @@ extern "C" int dkd_blocks_fwd(const DkdBlock* blocks, int32_t n_blocks, void* st
   for (int i = 0; i < n_blocks; ++i) {
     const DkdBlock& b = blocks[i];
     DKD_CHECK_ARG(b.x && b.x1 && b.x2 && b.y1 && b.qkv && b.o && b.y2 && b.h, "blocks_fwd: block %d has a null buffer", i);
+    DKD_CHECK_ARG(!b.fuse_attn || (b.D == 192 && b.H == 3 && b.N <= 208), "blocks_fwd: block %d: fuse_attn needs D = 192, H = 3, N <= 208", i);
     DKD_CHECK_ARG(!b.fuse_mlp || (b.D == 192 && b.hidden % 64 == 0 && b.fc2_wt), "blocks_fwd: block %d: fuse_mlp needs D = 192, hidden %% 64 == 0 and fc2_wt", i);
     DKD_CHECK_ARG(!b.ln_fold || (!b.pre && !b.fuse_mlp && !b.s1 && !b.s2 && b.xb && (!(b.ln_fold & 1) || (b.stats1 && b.qkv_c)) &&
                                  (!(b.ln_fold & 2) || (b.stats2 && b.fc1_c)) && (!(b.ln_fold & 4) || b.stats_next)),

@@ -57,7 +57,7 @@ class Block(C.Structure):
                                            "s1", "s2", "x", "x1", "x2", "y1", "qkv", "o", "y2", "pre", "h", "tap",
                                            "mean1", "rstd1", "mean2", "rstd2", "lse")] + [("fuse_mlp", C.c_int32), ("ln_fold", C.c_int32)] +
                 [(n, C.c_void_p) for n in ("qkv_c", "fc1_c", "stats1", "stats2", "stats_next", "xb")] + [("ln1_ready", C.c_int32)] +
-                [(n, C.c_void_p) for n in ("next_ln1_w", "next_ln1_b", "next_y1", "next_mean1", "next_rstd1")])
+                [(n, C.c_void_p) for n in ("next_ln1_w", "next_ln1_b", "next_y1", "next_mean1", "next_rstd1")] + [("fuse_attn", C.c_int32)])
 
 
 class BlockGrads(C.Structure):
@@ -81,6 +81,7 @@ _SIGS = {
     "dkd_gemm_tn": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                               C.c_int32, RowMap, RowMap, C.c_void_p, C.c_void_p]),
     "dkd_gemm_tn_group": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
+    "dkd_attn192_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "dkd_block_wgrad_group": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
     "dkd_ln_bwd_reduce_group": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
     "dkd_conv3x3_wgrad": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),

@@ -147,6 +147,16 @@ def attn_fwd(qkv, B, N, H, need_lse=True):
     return out, lse
 
 
+def attn192_fwd(y1, wqkv, bqkv, B, N, need_lse=True):
+    """y1 bf16 [B*N, 192], wqkv bf16 [576, 192], bqkv f32 [576] -> (qkv bf16 [B*N, 576], out bf16 [B*N, 192], lse f32 [B, 3, N] | None)."""
+    assert y1.dtype == BF16 and y1.is_contiguous() and wqkv.dtype == BF16 and wqkv.is_contiguous() and bqkv.dtype == F32
+    qkv = torch.empty(B * N, 576, device=y1.device, dtype=BF16)
+    out = torch.empty(B * N, 192, device=y1.device, dtype=BF16)
+    lse = torch.empty(B, 3, N, device=y1.device, dtype=F32) if need_lse else None
+    check(lib().dkd_attn192_fwd(ptr(y1), ptr(wqkv), ptr(bqkv), ptr(qkv), ptr(out), ptr(lse), B, N, stream()), "attn192_fwd")
+    return qkv, out, lse
+
+
 def attn_bwd(qkv, out, dout, lse, B, N, H):
     assert dout.dtype == BF16 and dout.is_contiguous() and out.is_contiguous() and qkv.is_contiguous()
     dqkv = torch.empty_like(qkv)

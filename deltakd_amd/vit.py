@@ -284,6 +284,11 @@ def mlp_fusion_enabled(D, hidden):
     return D == 192 and hidden % 64 == 0 and not os.environ.get("DKD_NO_MLP_FUSION")
 
 
+def attn_fusion_enabled(D, H, N):
+    """The fused qkv + attention kernel (csrc/attn192.hip) takes the DeiT-tiny shape; DKD_NO_ATTN_FUSION=1 keeps the two launches (A/B)."""
+    return D == 192 and H == 3 and N <= 208 and not os.environ.get("DKD_NO_ATTN_FUSION")
+
+
 def _fill_weights(bs: ffi.Block, blk: Block, sh: Shadow, B, N, backward: bool):
     D = blk.norm1.weight.numel()
     bs.B, bs.N, bs.D, bs.H, bs.hidden, bs.eps = B, N, D, blk.attn.num_heads, blk.mlp.fc1.out_features, blk.norm1.eps
@@ -294,6 +299,7 @@ def _fill_weights(bs: ffi.Block, blk: Block, sh: Shadow, B, N, backward: bool):
     bs.qkv_w, bs.proj_w = sh.get(a.qkv.weight).data_ptr(), sh.get(a.proj.weight).data_ptr()
     bs.fc1_w, bs.fc2_w = sh.get(m.fc1.weight).data_ptr(), sh.get(m.fc2.weight).data_ptr()
     if not backward:                     # (the backward runs on the descriptor the forward filled: the flag is decided once)
+        bs.fuse_attn = 1 if attn_fusion_enabled(D, blk.attn.num_heads, N) else 0
         bs.fuse_mlp = 1 if mlp_fusion_enabled(D, m.fc1.out_features) else 0
         if bs.fuse_mlp:
             bs.fc2_wt = sh.get(m.fc2.weight, transposed=True).data_ptr()     # the fused forward reads fc2's weight transposed

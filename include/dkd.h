@@ -183,6 +183,11 @@ int dkd_mlp192_fwd(const float* x1, const float* ln_w, const float* ln_b, float 
                    const void* fc2_wt, const float* fc2_b, const float* rowscale, int32_t rows_per_sample, float* x2, void* tap, void* y2,
                    void* pre, void* h, float* mean, float* rstd, const float* next_ln_w, const float* next_ln_b, void* next_y,
                    float* next_mean, float* next_rstd, int32_t M, int32_t hidden, void* stream);
+/* The qkv projection and the attention of a D = 192, 3-head block in one launch ([3P] timm Attention.forward up to proj; one workgroup per
+ * sample, N <= 208): qkv bf16 [B*N, 576] = y1 Wqkv^T + b (written once, for the backward), o bf16 [B*N, 192] = softmax(q k^T / 8) v per
+ * head, lse f32 [B, 3, N] (may be NULL).  y1 bf16 [B*N, 192] (norm1 output), wqkv bf16 [576, 192], bqkv f32 [576].  Same results as
+ * dkd_gemm_nt(BIAS) + dkd_attn_fwd up to the summation order (DkdBlock.fuse_attn selects it). */
+int dkd_attn192_fwd(const void* y1, const void* wqkv, const float* bqkv, void* qkv, void* o, float* lse, int32_t B, int32_t N, void* stream);
 int dkd_mlp192_bwd(float* g, const void* gtap, const float* s2, const float* s1, int32_t rows_per_sample, const void* pre,
                    const void* fc2_wt, const void* fc1_w, const float* x1, const float* ln_w, const float* mean, const float* rstd, void* dF,
                    void* dH, void* cast_out, float* d_ln_w, float* d_ln_b, float* ws, int32_t M, int32_t hidden, void* stream);
@@ -322,6 +327,7 @@ typedef struct {
   const float *next_ln1_w, *next_ln1_b;   /* with fuse_mlp, optional: the next block's norm1 parameters and buffers (see dkd_mlp192_fwd) */
   void* next_y1;
   float *next_mean1, *next_rstd1;
+  int32_t fuse_attn;                 /* 1: qkv projection + attention run on dkd_attn192_fwd (D = 192, H = 3, N <= 208; not with ln_fold) */
 } DkdBlock;
 
 /* A deferred LayerNorm parameter-gradient reduction: dgamma[c] += sum_b part[b][c], dbeta[c] += sum_b part[b][D + c] over nblk

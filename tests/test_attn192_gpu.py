@@ -1,0 +1,69 @@
+"""The fused qkv projection + attention kernel of the D = 192 student (csrc/attn192.hip, dkd_attn192_fwd) against fp32 torch and against
+the two launches it replaces (dkd_gemm_nt with bias + dkd_attn_fwd), through the C ABI."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+BF16, F32 = torch.bfloat16, torch.float32
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from deltakd_amd import ops as o
+    o.lib()
+    return o
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def rnd(*shape, scale=1.0, seed=0):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(dev())
+
+
+def close(got, ref, rel, what=""):
+    got, ref = got.float(), ref.float()
+    err = (got - ref).abs().max().item()
+    scale = ref.abs().max().item() + 1e-12
+    assert math.isfinite(err) and err <= rel * scale, f"{what}: max abs err {err:.4e} vs scale {scale:.4e} (rel {err/scale:.3e} > {rel})"
+
+
+@pytest.mark.parametrize("B,N", [(2, 17), (3, 65), (5, 197), (4, 198), (3, 208), (2, 16), (300, 197), (1, 1)])
+def test_attn192_fwd(ops, B, N):
+    """qkv (bf16, rounded once from the fp32 accumulator like the GEMM's epilogue), the attention output and the log-sum-exp:
+    against fp32 torch on the bf16 operands (qkv 1e-2: bf16 output rounding; out 2e-2: it also sees the rounded q, k, v and P) and
+    against the unfused launches (same arithmetic, different summation order).  B = 300 exceeds the CU count (the persistent loop over
+    samples); N = 208 fills the last key tile, N = 16 / 17 / 65 leave most key tiles to the padding mask, N = 1 is a single token."""
+    H, D = 3, 192
+    y1 = rnd(B * N, D, seed=1).to(BF16)
+    w = rnd(3 * D, D, scale=D ** -0.5, seed=2).to(BF16)
+    bias = rnd(3 * D, scale=0.5, seed=3)
+    qkv, out, lse = ops.attn192_fwd(y1, w, bias, B, N)
+    ref_qkv = y1.float() @ w.float().t() + bias
+    close(qkv, ref_qkv, 1e-2, "qkv")
+    q, k, v = qkv.float().view(B, N, 3, H, 64).permute(2, 0, 3, 1, 4)          # attention reference on the kernel's own (rounded) qkv
+    s = (q @ k.transpose(-1, -2)) * 0.125
+    ref = (s.softmax(-1) @ v).transpose(1, 2).reshape(B * N, D)
+    close(out, ref, 1.5e-2, "attention out")
+    close(lse, torch.logsumexp(s, -1), 1e-3, "lse")
+    # the launches it replaces
+    qkv_u = ops.gemm_nt(y1, w, bias=bias)
+    out_u, lse_u = ops.attn_fwd(qkv_u, B, N, H)
+    close(qkv, qkv_u, 8e-3, "qkv vs the GEMM launch")                            # (one bf16 ulp where the fp32 sums round differently)
+    close(out, out_u, 1.5e-2, "out vs the attention launch")
+    close(lse, lse_u.view(B, H, N), 1e-3, "lse vs the attention launch")
+
+
+def test_attn192_refuses_what_it_does_not_take(ops):
+    from deltakd_amd import ffi
+    y1 = rnd(209, 192).to(BF16)
+    w = rnd(576, 192).to(BF16)
+    b = rnd(576)
+    qkv = torch.empty(209, 576, device=dev(), dtype=BF16)
+    o = torch.empty(209, 192, device=dev(), dtype=BF16)
+    rc = ffi.lib().dkd_attn192_fwd(ffi.ptr(y1), ffi.ptr(w), ffi.ptr(b), ffi.ptr(qkv), ffi.ptr(o), None, 1, 209, ffi.stream())
+    assert rc != 0 and b"208" in ffi.lib().dkd_last_error()

@@ -185,16 +185,18 @@ def test_fast_gelu_keeps_nan(ops):
 
 @pytest.mark.parametrize("B,tap_layers,droppath", [(3, (0, 1), 0.1), (6, (), 0.0)])
 def test_block_with_fused_mlp_equals_the_unfused_launch_sequence(B, tap_layers, droppath, monkeypatch):
-    """Whole DeiT-tiny-width blocks (D = 192, hidden 768, N = 197) forward + backward with the fused MLP kernels against the same model
-    on the separate launches (DKD_NO_MLP_FUSION=1): logits, taps, every parameter gradient.  Both paths round the same tensors to bf16
+    """Whole DeiT-tiny-width blocks (D = 192, hidden 768, N = 197) forward + backward with the fused MLP kernels and the fused qkv +
+    attention kernel against the same model on the separate launches (DKD_NO_MLP_FUSION=1, DKD_NO_ATTN_FUSION=1): logits, taps, every
+    parameter gradient.  Both paths round the same tensors to bf16
     at the same places, so they agree far inside the bf16-vs-fp32 parity tolerance."""
     from deltakd_amd import vit
 
     def run(no_fusion):
-        if no_fusion:
-            monkeypatch.setenv("DKD_NO_MLP_FUSION", "1")
-        else:
-            monkeypatch.delenv("DKD_NO_MLP_FUSION", raising=False)
+        for knob in ("DKD_NO_MLP_FUSION", "DKD_NO_ATTN_FUSION"):       # the unfused run also takes the separate qkv GEMM + attention launches
+            if no_fusion:
+                monkeypatch.setenv(knob, "1")
+            else:
+                monkeypatch.delenv(knob, raising=False)
         torch.manual_seed(0)
         m = vit.VisionTransformer(192, 2, 3, 10, False, droppath).to(dev()).train()
         with torch.no_grad():
@@ -214,7 +216,7 @@ def test_block_with_fused_mlp_equals_the_unfused_launch_sequence(B, tap_layers, 
 
     z_f, t_f, g_f = run(False)
     z_u, t_u, g_u = run(True)
-    close(z_f, z_u, 5e-3, "logits")      # two bf16 pipelines with different accumulation orders (parity vs fp32: 2e-2)
+    close(z_f, z_u, 8e-3, "logits")      # two bf16 pipelines (MLP and attention branch) with different accumulation orders (parity vs fp32: 2e-2)
     for a, b in zip(t_f, t_u):
         close(a, b, 1e-2, "tap")
     worst = max((rel_l2(g_f[n], g_u[n]), n) for n in g_u if g_u[n].norm() > 0)

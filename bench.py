@@ -220,8 +220,11 @@ def main():
     side_saved, criterion.teacher_stream = criterion.teacher_stream, None
     wg_saved = os.environ.get("DKD_NO_WGRAD_OVERLAP")
     os.environ["DKD_NO_WGRAD_OVERLAP"] = "1"
+    ev_p0, ev_p1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev_p0.record()
     ops.probe_begin()
     stats = run(1)
+    ev_p1.record()
     criterion.teacher_stream = side_saved
     if wg_saved is None:
         del os.environ["DKD_NO_WGRAD_OVERLAP"]
@@ -231,6 +234,7 @@ def main():
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = tmax.item()
+    probe_step_ms = ev_p0.elapsed_time(ev_p1)         # the single-stream, event-instrumented last step (part of `value`; steady-state steps are shorter)
 
     # dominant kernel = the NT-GEMM symbol with the largest summed duration in the last timed step (teacher forward is
     # ~82 % of the step's FLOPs); achieved = its algorithmic FLOPs (2 M N K per launch) / its HIP-event time.
@@ -273,6 +277,8 @@ def main():
         "metric": f"images/sec (whole node) DeiT-tiny<-DeiT-base distill, bs={a.batch}/GPU", "value": ips, "unit": "images/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "probed_last_step_ms": probe_step_ms,
+        "steady_ms_per_step": (dt * 1e3 - probe_step_ms) / max(a.steps - 1, 1) if a.steps > 1 else None,
         "config": {"workload": f"exp/{a.config}-deit-tiny.sh: {cfg['student']} <- {cfg['teacher']}, {cfg['distillation_type']}, "
                                f"bs {a.batch}/GPU, 3x224x224 synthetic ({n_distinct} distinct batches rotated), 1000 classes, mixup/cutmix on, drop_path 0.1, AdamW",
                    "global_batch": world * a.batch, "parallelism": f"dp{world}",

@@ -28,7 +28,9 @@ teacher, student = load_teacher_student_model(cfg["teacher"], cfg["student"], ar
 student.to(dev)
 teacher.to(dev)
 opt = create_optimizer(args, student)
-crit = DistillationLoss(call_base_loss(args), teacher, cfg["distillation_type"], args.alpha, args.tau, teacher_stream=torch.cuda.Stream())
+prio = int(os.environ.get("DKD_TEACHER_PRIO", "0"))          # (A/B: -1 = high-priority hardware queue for the teacher stream)
+crit = DistillationLoss(call_base_loss(args), teacher, cfg["distillation_type"], args.alpha, args.tau,
+                        teacher_stream=torch.cuda.Stream(priority=prio))
 mix = Mixup(mixup_alpha=args.mixup, cutmix_alpha=args.cutmix, prob=args.mixup_prob, switch_prob=args.mixup_switch_prob,
             label_smoothing=args.smoothing, num_classes=1000)
 pool = [(torch.randn(batch, 3, 224, 224, device=dev), torch.randint(0, 1000, (batch,), device=dev)) for _ in range(4)]

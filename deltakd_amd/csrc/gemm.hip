@@ -483,7 +483,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const DkdGemm g, const 
 // and nothing else), 0 otherwise.  Known, the waits that follow an epilogue count its stores as outstanding instead of draining
 // them: they retire under the next tile's first phases.
 // ABL: dev-only ablation bits (build with -DDKD_NT256_ABL=n; results are then wrong, timings are the point): 1 no epilogue,
-// 2 two units per tile, 4 no LDS-DMA in the loop, 8 no barriers, 16 no fragment reads, 32 no MFMAs.
+// 2 two units per tile, 4 no LDS-DMA in the loop, 8 no barriers, 16 no fragment reads, 32 no MFMAs, 64 LDS-DMA pieces of full 128-byte lines.
 // WN: waves along N.  4: the 256 x 256 tile, 8 waves, ring of 5 units, one workgroup per CU (qkv / fc1 of the teacher).
 //     2: a 256 x 128 tile, 4 waves, ring of 3 units (72 KiB), two workgroups per CU -- for N = 768 (proj / fc2), where 256-wide
 //        tiles leave 256 CUs with 2.3 rounds of work; it moves 25 % less operand data through the LDS-DMA path than the
@@ -570,7 +570,15 @@ __global__ __launch_bounds__(128 * WN, WN == 4 ? 1 : 2) void gemm_nt256_kernel(c
     const uint32_t dst = (uint32_t)(uintptr_t)LDS_PTR(smem) + slot * UNIT + (is_a ? 0 : WHALF) + row0 * 64;
     // SGPR base + 32-bit byte offset: half the address data of the 64-bit-per-lane form.  M0 (the LDS destination) is set inside
     // the statement and named as a clobber; nothing else in this kernel makes the compiler use M0.
-    const uint32_t voff = ((is_a ? aoff[is_a ? c : 0] : boff[is_a ? 0 : c - AP]) + ld_p * 32) * 2;
+    uint32_t voff = ((is_a ? aoff[is_a ? c : 0] : boff[is_a ? 0 : c - AP]) + ld_p * 32) * 2;
+    if (ABL & 64) {
+      // (ablation: the same bytes per unit as FULL 128-byte line segments -- 8 rows x 128 B per piece, rows 0-7 of the piece's 16 on even
+      // units and rows 8-15 on odd ones, columns of both units -- to see what 64-byte segments cost the texture path; LDS contents are garbage)
+      const uint32_t base = is_a ? aoff[is_a ? c : 0] : boff[is_a ? 0 : c - AP];
+      const uint32_t ld = is_a ? (uint32_t)g.lda : (uint32_t)g.ldb;
+      const uint32_t rowbase = base - (((lane >> 2) * ld) + ((base % ld) % 32));           // row 0 of the piece, column 0 of the tile's K range
+      voff = (rowbase + ((lane >> 3) + 8 * (ld_p & 1)) * ld + (lane & 7) * 8 + (ld_p >> 1) * 64) * 2;
+    }
 #pragma clang diagnostic push
 #pragma clang diagnostic ignored "-Winline-asm"
     if (is_a) asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(dst), "v"(voff), "s"(Ab) : "memory", "m0");

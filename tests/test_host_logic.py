@@ -122,6 +122,39 @@ def test_metric_logger_contract():
     assert seen == [0, 1, 2, 3, 4]
 
 
+def test_metric_logger_adds_the_tensor_meters_of_one_call_together():
+    """MetricLogger.update(a=, b=, c=) with 0-dim tensors accumulates them in one multi-tensor add (deltakd_amd.logger): totals, counts and
+    the window must equal the one-meter-per-call path; python numbers in the same call keep their own path."""
+    import torch
+    from deltakd_amd.logger import MetricLogger
+    a, b = MetricLogger(), MetricLogger()
+    g = torch.Generator().manual_seed(0)
+    for step in range(7):
+        vals = {"loss": torch.rand((), generator=g), "acc1": torch.rand((), generator=g) * 100, "acc5": torch.rand((), generator=g) * 100}
+        a.update(lr=1e-3 * step, **vals)
+        for k, v in vals.items():
+            b.update(**{k: v})
+        b.update(lr=1e-3 * step)
+    for k in ("loss", "acc1", "acc5", "lr"):
+        assert abs(a.meters[k].global_avg - b.meters[k].global_avg) < 1e-6 and a.meters[k].count == b.meters[k].count == 7
+        assert abs(a.meters[k].value - b.meters[k].value) < 1e-7
+    assert "loss" in str(a)
+
+
+def test_wgrad_group_size_knob(monkeypatch):
+    """deltakd_amd.vit.wgrad_group_size: default 6 blocks per deferred weight-gradient launch, a model attribute (data parallel sets its
+    bucket size) or DKD_WGRAD_GROUP override it, clamped to what dkd_block_wgrad_group takes (24 problems = 6 blocks)."""
+    from types import SimpleNamespace
+    from deltakd_amd import vit
+    monkeypatch.delenv("DKD_WGRAD_GROUP", raising=False)
+    assert vit.wgrad_group_size(SimpleNamespace()) == 6
+    assert vit.wgrad_group_size(SimpleNamespace(_wgrad_group=4)) == 4
+    monkeypatch.setenv("DKD_WGRAD_GROUP", "1")
+    assert vit.wgrad_group_size(SimpleNamespace(_wgrad_group=4)) == 1
+    monkeypatch.setenv("DKD_WGRAD_GROUP", "64")
+    assert vit.wgrad_group_size(SimpleNamespace()) == 6
+
+
 def test_error_behaviour_matches_reference():
     from deltakd_amd.losses import DistillationLoss, LabelSmoothingCrossEntropy
     from deltakd_amd.models import forward_with_features

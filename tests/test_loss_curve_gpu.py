@@ -29,8 +29,8 @@ class Recorder:
         return loss
 
 
-@pytest.mark.parametrize("kind", ["mgd", "lrkd"])
-def test_loss_curve_tracks_the_oracle_loop_over_120_steps(kind):
+@pytest.mark.parametrize("kind,width", [("mgd", 64), ("lrkd", 64), ("mgd", 192)])
+def test_loss_curve_tracks_the_oracle_loop_over_120_steps(kind, width):
     """Asserted (the measured values are in the assertion messages / printed):
       * the loss averaged over windows of 10 steps, at all 12 windows: product within 0.5 % of the oracle's (measured: 0.05 %);
       * the curves are curves: the oracle's last window is well below its first (the toy problem is learning, so an all-constant
@@ -39,7 +39,11 @@ def test_loss_curve_tracks_the_oracle_loop_over_120_steps(kind):
       * the trained models agree: eval-mode logits on 64 held-out images, relative L2 <= 0.05 (measured 0.008), and >= 95 % of the top-1
         decisions (measured: all).
     lrkd: the exact-SVD targets of every step are computed once from the (frozen) oracle teacher on the mixed batches and replayed to
-    both loops, as in tests/test_engine_gpu.py (the SVD's column signs are arbitrary)."""
+    both loops, as in tests/test_engine_gpu.py (the SVD's column signs are arbitrary).
+    width 192 (3 heads): the student takes the fused kernels of the headline path -- dkd_attn192_fwd, dkd_mlp192_fwd / _bwd, weight gradients
+    and LayerNorm reductions deferred six blocks at a time -- for all 120 free-running steps (at a third of the learning rate: at 1e-3
+    this 12-block, 192-wide model's loss on 240 images starts to oscillate after ~80 steps, in the oracle too, and two runs that agreed to
+    1e-4 until then separate by 0.6 % over the next 40 -- sensitivity of the trajectory, not of the arithmetic)."""
     from oracle import engine_ref, loss_ref, vit_ref
     from deltakd_amd import vit
     from deltakd_amd.engine import train_one_epoch
@@ -50,12 +54,13 @@ def test_loss_curve_tracks_the_oracle_loop_over_120_steps(kind):
     torch.manual_seed(21)
     C, B, n_batches, epochs, depth, size = 10, 8, 30, 4, 12, 32
     args = loss_ref.default_args(distillation_type=kind, dataset="cifar-10", mgd_alpha=2.0, mgd_mask_ratio=0.5, alpha=0.5, tau=3.0,
-                                 lrkd_rank=16, opt="adamw", lr=1e-3, weight_decay=0.05, opt_eps=1e-8, opt_betas=None, mixup=0.8, cutmix=1.0,
+                                 lrkd_rank=16, opt="adamw", lr=1e-3 if width == 64 else 3e-4, weight_decay=0.05, opt_eps=1e-8, opt_betas=None, mixup=0.8, cutmix=1.0,
                                  smoothing=0.1, epochs=epochs, print_freq=100000, rank=1)
     o_t = vit_ref.VisionTransformerRef(128, depth, 2, C, True, 0.0, **TOY).eval()
-    o_s = vit_ref.VisionTransformerRef(64, depth, 1, C, False, 0.1, **TOY).train()
+    heads = width // 64
+    o_s = vit_ref.VisionTransformerRef(width, depth, heads, C, False, 0.1, **TOY).train()
     t = vit.VisionTransformer(128, depth, 2, C, True, 0.0, **TOY)
-    s = vit.VisionTransformer(64, depth, 1, C, False, 0.1, **TOY)
+    s = vit.VisionTransformer(width, depth, heads, C, False, 0.1, **TOY)
     loss_ref.attach_aux_ref(o_s, o_t, kind, args.lrkd_rank)
     attach_aux(s, t, kind, args)
     with torch.no_grad():
@@ -79,7 +84,7 @@ def test_loss_curve_tracks_the_oracle_loop_over_120_steps(kind):
     n_steps = epochs * n_batches
     keeps = [[(torch.rand(B, generator=g) > 0.1).float() for _ in range(2 * depth)] for _ in range(n_steps)]
     noises = [torch.rand(B, (size // 8) ** 2, generator=g) for _ in range(n_steps)]
-    sched_kw = dict(t_initial=epochs, lr_min=1e-5, warmup_t=1, warmup_lr_init=2e-4)
+    sched_kw = dict(t_initial=epochs, lr_min=1e-5, warmup_t=1, warmup_lr_init=2e-4 if width == 64 else 1e-4)
     o_mix = engine_ref.MixupRef(mixup_alpha=0.8, cutmix_alpha=1.0, label_smoothing=0.1, num_classes=C)
 
     draws = [{"noise": n} for n in noises]

@@ -125,6 +125,32 @@ def cpu_baseline(cfg, batch=32, warmup=2, steps=10, budget_s=75.0):
                       f"torch CPU, {threads} threads on {cpus} usable of {os.cpu_count()} logical cpus, {model})"}
 
 
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher: run `python -m torch.distributed.run --nproc-per-node N bench.py <same args>`
+    as a CHILD process (the reference's launch line: exp/lrkd-deit-tiny.sh:14, tools/utils.py:52-63), relay its output (rank 0
+    prints the JSON line) and return its exit code.  Nothing in this parent touches the GPU: `torch.cuda.device_count()` does not
+    initialise it on this image, and a process that has must not exec another program on this pool."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()
+    if have < n and os.environ.get("DKD_DIST_BACKEND", "nccl") == "nccl":
+        missing = ", ".join(f"cuda:{i}" for i in range(have, n))
+        print(f"bench.py: --gpus {n} needs {n} GPUs on this node but only {have} "
+              f"{'is' if have == 1 else 'are'} visible: missing device(s) {missing}.  One rank per GPU over RCCL cannot start; "
+              f"run with --gpus {max(have, 1)} here (DKD_DIST_BACKEND=gloo DKD_FORCE_DEVICE=0 rehearses the N > 1 code path "
+              f"on one card).", file=sys.stderr, flush=True)
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (_host_cpus()[0]) // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -135,6 +161,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-side-stream", action="store_true")
     a = ap.parse_args()
+
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(a.gpus))              # plain `python bench.py --gpus N`: start the N ranks ourselves (child process)
 
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -150,7 +179,11 @@ def main():
             dist.init_process_group("nccl", init_method="env://", device_id=torch.device("cuda", local))
         else:
             dist.init_process_group(backend, init_method="env://")
-    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N > 1"
+    if world != a.gpus:
+        sys.exit(f"bench.py: --gpus {a.gpus} but the launcher set WORLD_SIZE={world}; start it as `python bench.py --gpus {a.gpus}` "
+                 f"(it launches its own ranks) or with torch.distributed.run --nproc-per-node {a.gpus}")
+    if backend == "nccl" and "DKD_FORCE_DEVICE" not in os.environ and local >= torch.cuda.device_count():
+        sys.exit(f"bench.py: rank {rank} needs cuda:{local} but this host shows {torch.cuda.device_count()} GPU(s)")
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
 

@@ -133,7 +133,9 @@ __global__ __launch_bounds__(256) void topk_correct_kernel(const float* __restri
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= B) return;
   const float* zr = z + (size_t)row * C;
-  const int lab = (int)labels[row];
+  const int64_t lab64 = labels[row];
+  if (lab64 < 0 || lab64 >= C) return;   // ignore_index / a class the head does not have: never among the top k (timm counts it wrong)
+  const int lab = (int)lab64;
   const float t = zr[lab];
   int cnt = 0;
   for (int c = lane; c < C; c += 64) {

@@ -17,16 +17,19 @@ import torch.nn as nn
 
 
 class DataParallel(nn.Module):
-    def __init__(self, module, optimizer=None, bucket_bytes=8 << 20, overlap=True, process_group=None):
+    def __init__(self, module, optimizer=None, bucket_bytes=8 << 20, overlap=True, process_group=None, force=False):
+        """``force``: issue every collective even in a world of ONE rank (broadcast, bucket all-reduces on the comm stream, tail
+        sync).  A one-GPU box can then drive the whole path through the "nccl" backend (= RCCL); results equal the unwrapped model's."""
         super().__init__()
         self.module = module
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.active = self.world > 1 or (force and dist.is_initialized())
         self.bucket_bytes = bucket_bytes
         self._opt = optimizer
         self._comm_stream = None
         self._pending = []
-        if self.world > 1:
+        if self.active:
             with torch.no_grad():                      # rank 0's parameters win (DDP constructor semantics)
                 for t in list(module.parameters()) + list(module.buffers()):
                     dist.broadcast(t.data, src=0, group=process_group)
@@ -39,7 +42,7 @@ class DataParallel(nn.Module):
         self.bytes_reduced = 0
         if optimizer is not None and hasattr(optimizer, "grad_sync"):
             optimizer.grad_sync = self._sync_flat
-        self.overlap = overlap and self.world > 1 and optimizer is not None and hasattr(optimizer, "flat_grads")
+        self.overlap = overlap and self.active and optimizer is not None and hasattr(optimizer, "flat_grads")
         if self.overlap:
             self._plan = self._plan_overlap()
             if self._plan:
@@ -120,7 +123,7 @@ class DataParallel(nn.Module):
     def _sync_flat(self, flat_grads):
         """Called by FusedAdamW.step() before the update: reduce whatever the backward callbacks have not reduced yet
         (embedding, head, aux modules -- or everything when overlap is off) and join the comm stream."""
-        if self.world == 1:
+        if not self.active:
             return
         cur = torch.cuda.current_stream() if flat_grads[0].is_cuda else None
         todo = []
@@ -149,7 +152,7 @@ class DataParallel(nn.Module):
 
     def sync_gradients(self):
         """For optimizers without flat storage: coalesce ``p.grad`` into buckets, all-reduce, scatter back."""
-        if self.world == 1:
+        if not self.active:
             return
         grads = [p.grad for p in self.module.parameters() if p.requires_grad and p.grad is not None]
         bucket, size = [], 0

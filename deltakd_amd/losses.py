@@ -374,9 +374,15 @@ class DistillationLoss(nn.Module):
         if fwt is None:
             raise RuntimeError("teacher model has no forward_with_taps(); build it with deltakd_amd.vit.create_model")
         # (the teacher's logits feed soft / hard only -- model/loss.py:57-67; the feature criteria read its taps: no head launches)
-        try:
+        if self._fwt_takes_head is None:                # a foreign model's forward_with_taps may lack the keyword: looked up once
+            import inspect
+            try:
+                self._fwt_takes_head = "head" in inspect.signature(fwt).parameters
+            except (TypeError, ValueError):
+                self._fwt_takes_head = False
+        if self._fwt_takes_head:
             logits, taps = fwt(inputs, self._TAPS.get(kind), head=False)
-        except TypeError:                               # a foreign model's forward_with_taps without the keyword
+        else:
             logits, taps = fwt(inputs, self._TAPS.get(kind))
         pt = getattr(_unwrap(t), "num_prefix_tokens", 2)
         want_tgt = kind == "lrkd" and "lrkd_targets" not in self.injected

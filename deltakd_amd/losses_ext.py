@@ -220,6 +220,13 @@ def curkd_loss(student_model, student_features, teacher_features, args, *, npre_
     """model/loss.py:362-420: epoch curriculum -- blocks 0-2 (epoch < 100), blocks 3-6 (< 151), then masked generation on block 11."""
     sm = student_model
     epoch = args.current_epoch
+    # tell the optimizer which stage is in use this step (an explicit device flag per lazy unit: a used stage whose gradient happens
+    # to be exactly zero must still be updated -- weight decay, moment decay -- as torch.optim.AdamW does; deltakd_amd.optim)
+    stage = sm.curkd_align_early if epoch < 100 else sm.curkd_align_mid if epoch < 151 else sm.curkd_align_last
+    if torch.is_grad_enabled():
+        flag = getattr(next(stage.parameters()), "dkd_unit_touched", None)
+        if flag is not None:
+            flag.fill_(1.0)
     if epoch < 100:
         layers, mods, div = range(3), sm.curkd_align_early, 3.0
     elif epoch < 151:

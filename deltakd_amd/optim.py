@@ -44,6 +44,7 @@ class FusedAdamW(torch.optim.Optimizer):
         self._step = 0
         self._units = {}               # lazy unit -> device f32 [2]: (largest |g| this step, the unit's own step count)
         self._unit_segs = {}           # lazy unit -> [(flat index, start, end)]
+        self._touched = {}             # lazy unit -> device f32 scalar the loss sets to 1 when it uses the unit (``p.dkd_unit_touched``)
         self.grad_sync = None          # set by deltakd_amd.ddp: called with the flat grad buffers before the update
         self._synced = False           # gradients of the current iteration already averaged (sync_grads() ran ahead of step())
         self._flatten()
@@ -85,6 +86,8 @@ class FusedAdamW(torch.optim.Optimizer):
                 bound_params.append(p)
                 self._where[id(p)] = (len(self._flat), off, off + n)
                 unit = getattr(p, "dkd_lazy_unit", None)
+                if unit is not None:
+                    p.dkd_unit_touched = self._touched.setdefault(unit, torch.zeros((), device=dev, dtype=F32))
                 if segments and segments[-1][2] == unit:
                     segments[-1][1] = off + n
                 else:
@@ -155,7 +158,10 @@ class FusedAdamW(torch.optim.Optimizer):
         self._synced = False
         self._step += 1
         for unit, state in self._units.items():           # did anything write a gradient for this unit?  (device side: no host sync)
-            gate = torch.stack([self._flat[i]["g"][s0:e0].abs().amax() for i, s0, e0 in self._unit_segs[unit]]).amax()
+            # "a gradient was written": the loss said so (explicit flag) or some element is non-zero (losses that do not flag)
+            gate = torch.stack([self._flat[i]["g"][s0:e0].abs().amax() for i, s0, e0 in self._unit_segs[unit]]
+                               + [self._touched[unit]]).amax()
+            self._touched[unit].zero_()
             state[0] = gate
             state[1] += (gate > 0).to(F32)
         for group, f in zip(self.param_groups, self._flat):
@@ -206,6 +212,14 @@ class FusedAdamW(torch.optim.Optimizer):
         if len(groups) != len(self.param_groups):
             raise ValueError("loaded state dict has a different number of parameter groups")
         steps = set()
+        # state the checkpoint does not hold (torch omits parameters that never had a gradient: a curkd stage before its epochs) is
+        # RESET, not left at the live optimizer's values: zero moments, zero step count
+        for f in self._flat:
+            if f is not None:
+                f["m"].zero_()
+                f["v"].zero_()
+        for st in self._units.values():
+            st.zero_()
         for group, f, saved in zip(self.param_groups, self._flat, groups):
             if len(saved["params"]) != len(group["params"]):
                 raise ValueError("loaded state dict contains a parameter group that doesn't match the size of optimizer's group")

@@ -543,7 +543,8 @@ def _blocks_forward_infer(x, B, N, model, scales, want):
     M, D = x.shape
     Hd = blocks[0].mlp.fc1.out_features
     dev = x.device
-    fold = ln_fold_supported(M, D, Hd) and all(s is None for s in scales)
+    guard = _rt(model).setdefault("ln_fold_guard", {"calls": 0, "pending": None, "off": False, "worst": 0.0})
+    fold = ln_fold_supported(M, D, Hd) and all(s is None for s in scales) and not guard["off"]
     # The descriptor table, the activation slab and the statistics buffers of a frozen model are the same from call to call: filling 12
     # descriptors (bf16 shadows, folded weights, ~40 ctypes fields each) cost ~0.28 ms of host time per teacher call, during which both
     # streams sat idle (kernel trace of round 3).  They are cached per (shape, taps, parameter state); a call only patches the pointers
@@ -597,8 +598,69 @@ def _blocks_forward_infer(x, B, N, model, scales, want):
         if i in want:
             taps[i] = torch.empty(M, D, device=dev, dtype=BF16)
             bs.tap = taps[i].data_ptr()
+    # the activation slab / statistics buffers are reused from call to call: a call on ANOTHER stream than the previous one (a
+    # teacher-stream prefetch followed by a main-stream fallback) first waits for that call's kernels
+    cur = torch.cuda.current_stream(dev)
+    last = rt.get("infer_done")
+    if last is not None and last[0] != cur.cuda_stream:
+        cur.wait_event(last[1])
     ffi.check(ffi.lib().dkd_blocks_fwd(arr, depth, ffi.stream()), "blocks_fwd")
-    return x, taps
+    ev = last[1] if last is not None else torch.cuda.Event()
+    ev.record(cur)
+    rt["infer_done"] = (cur.cuda_stream, ev)
+    redo = _ln_fold_check(guard, stats, D) if fold else False
+    return x, taps, redo
+
+
+LN_FOLD_MAX_OFFSET = float(os.environ.get("DKD_LN_FOLD_MAX_OFFSET", "3.0"))
+LN_FOLD_CHECK_EVERY = 64
+
+
+def _ln_fold_check(guard, stats, D):
+    """Guard of the LayerNorm fold.  The fold rounds x to bf16 BEFORE it is centred: an element's rounding error is
+    2^-9 |x_i| instead of 2^-9 |x_i - mu|, i.e. the error of the normalised row grows by sqrt(1 + (mu / sigma)^2) -- nothing for the
+    near-zero-mean rows of a random-init teacher or for a few massive channels (those round relative to themselves either way), but
+    a row with a COMMON offset |mu| >> sigma loses (mu / sigma) x in accuracy (tests/test_fullsize_gpu.py::
+    test_layernorm_fold_rows_with_a_common_offset measures it).  The producers' row statistics are already in HBM, so the worst
+    |mu| / sigma over all rows and layers costs one small reduction: it is taken on the model's first folded call (synchronously:
+    that call is redone unfolded if it fails) and on every 64th call after it (read back asynchronously, acted on a few calls later).
+    Above DKD_LN_FOLD_MAX_OFFSET (3: at most ~3.2x the unfolded path's rounding noise) the model drops back to the separate
+    LayerNorm launches for good.  Returns True when THIS call must be redone."""
+    n = guard["calls"]
+    guard["calls"] = n + 1
+    pend = guard["pending"]
+    if pend is not None and pend[1].query():
+        guard["pending"] = None
+        guard["worst"] = max(guard["worst"], float(pend[0]))
+        if float(pend[0]) > LN_FOLD_MAX_OFFSET:
+            _ln_fold_disable(guard, float(pend[0]))
+    if n % LN_FOLD_CHECK_EVERY:
+        return False
+    with torch.no_grad():
+        mu = stats[..., 0] / D
+        var = (stats[..., 1] / D - mu * mu).clamp_min(0.0)
+        ratio = (mu.abs() * torch.rsqrt(var + 1e-6)).amax()
+    if n == 0:
+        worst = float(ratio)                       # one host sync, on the first call of the model's life
+        guard["worst"] = worst
+        if worst > LN_FOLD_MAX_OFFSET:
+            _ln_fold_disable(guard, worst)
+            return True
+        return False
+    host = torch.empty((), dtype=F32, pin_memory=True)
+    host.copy_(ratio, non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record()
+    guard["pending"] = (host, ev)
+    return False
+
+
+def _ln_fold_disable(guard, worst):
+    import warnings
+    guard["off"] = True
+    warnings.warn(f"deltakd_amd: LayerNorm fold switched off for this model: rows with |mean| / std = {worst:.1f} > "
+                  f"{LN_FOLD_MAX_OFFSET} (bf16 rounding before centring would cost that factor in accuracy); the separate LayerNorm "
+                  f"kernels run from here on", RuntimeWarning)
 
 
 class _BlockFn(torch.autograd.Function):
@@ -819,7 +881,12 @@ class VisionTransformer(nn.Module):
         grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
         scales = self._droppath_scales(B, img.device)
         if grad:
-            _rt(self).pop("wgrad_pending", None)      # (only non-empty here after a backward pass that died half-way: stale, dropped)
+            stale = _rt(self).get("wgrad_pending")
+            if stale:
+                # weight gradients of up to six blocks wait for their grouped launch: a grad-mode forward in the MIDDLE of a backward
+                # pass (activation-checkpoint recompute, a forward inside a hook) must not lose them -- flush first.  After a backward
+                # pass that died half-way they are garbage the next zero_grad() clears anyway.
+                flush_wgrads(self)
             x = _EmbedFn.apply(self.pos_embed, self, img)
             for i in range(depth):
                 x, tap = _BlockFn.apply(x, self, i, B, N, scales[2 * i], scales[2 * i + 1], i in want)
@@ -827,7 +894,10 @@ class VisionTransformer(nn.Module):
                     taps[i] = tap.view(B, N, self.embed_dim)
         else:
             x, _ = self._embed(img)
-            x, flat_taps = _blocks_forward_infer(x, B, N, self, scales, want)
+            x, flat_taps, redo = _blocks_forward_infer(x, B, N, self, scales, want)
+            if redo:                                  # the LayerNorm-fold guard tripped on this model's first call: again, unfolded
+                x, _ = self._embed(img)
+                x, flat_taps, _ = _blocks_forward_infer(x, B, N, self, scales, want)
             for i, tap in enumerate(flat_taps):
                 if tap is not None:
                     taps[i] = tap.view(B, N, self.embed_dim)

@@ -10,6 +10,7 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box with -m gpu)")
+    config.addinivalue_line("markers", "real_curve: the 30-step loss curve at the real DeiT widths (deselect with -m 'gpu and not real_curve')")
 
 
 def pytest_collection_modifyitems(config, items):

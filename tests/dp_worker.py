@@ -23,8 +23,13 @@ def main():
     world, rank = int(os.environ["WORLD_SIZE"]), int(os.environ["RANK"])
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
-    if world > 1:
-        dist.init_process_group("gloo", init_method="env://")
+    backend = os.environ.get("DKD_DP_BACKEND", "gloo")          # "nccl" (= RCCL): the one-rank smoke of the real collective library
+    force = backend == "nccl"                                   # a world of one still issues every collective
+    if world > 1 or force:
+        if backend == "nccl":
+            dist.init_process_group("nccl", init_method="env://", device_id=dev)
+        else:
+            dist.init_process_group("gloo", init_method="env://")
     from oracle import loss_ref                      # default_args only (argument namespace); nothing of the oracle computes here
     from deltakd_amd import vit
     from deltakd_amd.ddp import DataParallel
@@ -52,8 +57,8 @@ def main():
     t.to(dev).eval()
     s.to(dev).train()
     opt = create_optimizer(args, s)
-    model = DataParallel(s, opt) if world > 1 else s
-    if world > 1 and rank == 0:
+    model = DataParallel(s, opt, force=force) if (world > 1 or force) else s
+    if (world > 1 or force) and rank == 0:
         print("overlap buckets:", sorted(model._plan or {}), flush=True)
     init = {n: p.detach().cpu().clone() for n, p in s.named_parameters()}
 
@@ -104,7 +109,13 @@ def main():
     if rank == 0:
         torch.save({"weights": {n: p.detach().cpu() for n, p in s.named_parameters()}, "init": init, "losses": [float(v) for v in lv],
                     "ranks_identical": identical, "clipped_steps": sum(int(float(n) > clip) for n in norms)}, out_path)
-    if world > 1:
+    if force and rank == 0:
+        maps = open("/proc/self/maps").read()
+        libs = sorted({ln.split()[-1] for ln in maps.splitlines() if "rccl" in ln.lower() or "libnccl" in ln.lower()})
+        print("backend:", dist.get_backend(), "| rccl mapped:", bool(libs), libs[:2], flush=True)
+        print("allreduce calls:", model.collectives, "bytes:", model.bytes_reduced, "comm stream used:",
+              model._comm_stream is not None, flush=True)
+    if world > 1 or force:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -10,6 +10,7 @@ order; the oracle side runs the fp32 torch restatement with torch.optim.AdamW ov
 import copy
 import json
 import os
+import re
 import socket
 import subprocess
 import sys
@@ -320,14 +321,14 @@ def _free_port():
         return sk.getsockname()[1]
 
 
-def _run_dp(world, clip, out_dir):
+def _run_dp(world, clip, out_dir, backend="gloo"):
     """Launch tests/dp_worker.py with ``world`` ranks (gloo, all on cuda:0) -> dict name -> weights after 2 steps (rank 0's)."""
     port = _free_port()
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   HSA_ENABLE_IPC_MODE_LEGACY="0")
-        out = os.path.join(out_dir, f"w{world}_c{clip}.pt")
+                   HSA_ENABLE_IPC_MODE_LEGACY="0", DKD_DP_BACKEND=backend)
+        out = os.path.join(out_dir, f"w{world}_c{clip}_{backend}.pt")
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dp_worker.py"), out, str(clip)], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     logs = []
@@ -342,6 +343,33 @@ def _run_dp(world, clip, out_dir):
     for p, lg in zip(procs, logs):
         assert p.returncode == 0, lg[-3000:]
     return torch.load(out, weights_only=True), logs
+
+
+def test_data_parallel_collectives_through_rccl_in_a_world_of_one(tmp_path):
+    """The data-parallel path on the "nccl" backend (= RCCL on ROCm), the library an 8-GPU run uses: one rank, wrapper forced active
+    (`DataParallel(force=True)`), so the parameter broadcast, the three bucket all-reduces launched from the block-backward callback
+    on the comm stream and the tail sync all go through RCCL on the real HIP model (reference: tools/train.py:307-308,
+    tools/utils.py:52-63).  In a world of one every collective is the identity: the weights after 2 steps must equal the unwrapped
+    model's (same bound as the 2-rank test: f32 atomics order differs between runs)."""
+    one, _ = _run_dp(1, 0.05, str(tmp_path))
+    rc, logs = _run_dp(1, 0.05, str(tmp_path), backend="nccl")
+    log = logs[0]
+    assert "backend: nccl" in log and "rccl mapped: True" in log, log[-2000:]
+    assert "overlap buckets: [0, 4, 8]" in log, log[-2000:]
+    m = re.search(r"allreduce calls: (\d+) bytes: (\d+) comm stream used: (\w+)", log)
+    assert m and int(m.group(1)) >= 2 * 4 and int(m.group(2)) > 0 and m.group(3) == "True", log[-2000:]
+    assert rc["clipped_steps"] == 2
+    for n in one["weights"]:
+        d0 = one["weights"][n] - one["init"][n]
+        d1 = rc["weights"][n] - rc["init"][n]
+        if d0.norm() == 0:
+            continue
+        if n.endswith("attn.qkv.bias"):
+            D = d0.numel() // 3
+            d0, d1 = torch.cat([d0[:D], d0[2 * D:]]), torch.cat([d1[:D], d1[2 * D:]])
+        cos = torch.nn.functional.cosine_similarity(d0.flatten().double(), d1.flatten().double(), dim=0).item()
+        assert cos > 0.98, (n, cos)
+    assert abs(one["losses"][0] - rc["losses"][0]) <= 1e-5 * abs(one["losses"][0])
 
 
 @pytest.mark.parametrize("clip", [0.0, 0.05])

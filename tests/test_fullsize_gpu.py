@@ -454,6 +454,80 @@ def test_layernorm_fold_consumer(ops, gelu):
         ops.gemm_nt(x[:512].to(BF16), wf, bias=bias, ln_stats=stats[:512].contiguous(), ln_c=bias)
 
 
+def rel2(got, ref):
+    return ((got.float() - ref.float()).norm() / ref.float().norm().clamp_min(1e-20)).item()
+
+
+@pytest.mark.parametrize("offset", [0.0, 3.0, 10.0, 50.0])
+def test_layernorm_fold_rows_with_a_common_offset(ops, offset):
+    """what the fold costs on rows a pretrained teacher produces and a random-init one does not -- a COMMON offset
+    (|row mean| = ``offset`` x the row's spread) plus a few massive channels (100 x).  The fold rounds x to bf16 before it is centred,
+    so an element's rounding error is 2^-9 |x_i| instead of 2^-9 |x_i - mu|: relative to the unfolded bf16 path the error grows like
+    sqrt(1 + offset^2); massive channels alone cost nothing (they are rounded relative to themselves either way).  Measured here
+    (relative L2 against fp32 LayerNorm -> Linear) and bounded by that model; the product keeps the fold only while the rows'
+    |mu| / sigma <= 3 (vit._ln_fold_check), i.e. within ~3.2 x the unfolded path's rounding noise."""
+    M, N, K = 16384 + 37, 4096, 768
+    x = rnd(M, K, seed=81)
+    x[:, [7, 300, 611]] *= 100.0                                  # massive channels
+    sigma = x.std(1, keepdim=True)
+    x = x + offset * sigma * (1.0 + 0.1 * rnd(M, 1, seed=82))     # the common offset, in units of each row's own spread
+    gamma, beta = 1.0 + 0.2 * rnd(K, seed=83), 0.1 * rnd(K, seed=84)
+    w = rnd(N, K, scale=0.04, seed=85)
+    bias = rnd(N, seed=86)
+    ref = torch.nn.functional.layer_norm(x.double(), (K,), gamma.double(), beta.double(), 1e-6).float() @ w.t() + bias
+    wf = (w * gamma[None, :]).to(BF16).contiguous()
+    stats = torch.stack([x.sum(1), (x * x).sum(1)], 1).contiguous()
+    got = ops.gemm_nt(x.to(BF16), wf, bias=(w @ beta + bias).contiguous(), ln_stats=stats, ln_c=wf.float().sum(1).contiguous())
+    y, _, _ = ops.layernorm_fwd(x, gamma, beta)
+    unfolded = ops.gemm_nt(y, w.to(BF16), bias=bias)
+    torch.cuda.synchronize()
+    e_fold, e_std = rel2(got, ref), rel2(unfolded, ref)
+    mu = x.mean(1)
+    ratio = (mu.abs() / x.var(1, unbiased=False).sqrt()).max().item()
+    model = math.sqrt(1.0 + ratio * ratio)
+    print(f"offset {offset}: worst |mu|/sigma {ratio:.2f}; folded {e_fold:.3e}, unfolded {e_std:.3e}, ratio {e_fold / e_std:.2f} (model {model:.2f})")
+    assert e_std < 5e-3
+    assert e_fold < 1.5 * model * e_std + 5e-4, (e_fold, e_std, model)
+    if offset <= 3.0:
+        assert e_fold < 2e-2                                      # inside the guard: the tolerance the tap comparisons use
+    # the guard itself, on these rows' statistics: keeps the fold up to its bound, drops it (and asks for a redo) beyond
+    from deltakd_amd import vit
+    guard = {"calls": 0, "pending": None, "off": False, "worst": 0.0}
+    import warnings
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
+        redo = vit._ln_fold_check(guard, stats[None], K)
+    assert abs(guard["worst"] - ratio) < 2e-2 * max(ratio, 1.0)
+    assert redo == (ratio > vit.LN_FOLD_MAX_OFFSET) and guard["off"] == redo and bool(caught) == redo
+
+
+def test_layernorm_fold_guard_on_a_teacher_with_offset_rows(monkeypatch):
+    """The guard end to end: a deit_base teacher whose residual stream carries a common offset (position embedding + 6: rows with
+    |mu| / sigma far above 3 from the first block on) must notice on its FIRST folded call, redo that call with the separate
+    LayerNorm kernels and stay there -- bit-identical to a DKD_NO_LN_FOLD=1 run; the same weights without the offset keep the fold."""
+    from deltakd_amd import vit
+    torch.manual_seed(4)
+    t = vit.create_model("deit_base_distilled_patch16_224", num_classes=1000).to(DEV).eval()
+    for p in t.parameters():
+        p.requires_grad = False
+    x = rnd(B, 3, 224, 224, seed=91)
+    with torch.no_grad():
+        t.forward_with_taps(x, (0, 11))
+        g0 = vit._rt(t)["ln_fold_guard"]
+        assert not g0["off"] and g0["calls"] == 1 and g0["worst"] < 1.0, g0      # random init: near-zero row means
+        t.pos_embed.add_(6.0)
+        vit._rt(t).pop("ln_fold_guard")
+        with pytest.warns(RuntimeWarning, match="LayerNorm fold switched off"):
+            z_g, taps_g = t.forward_with_taps(x, (0, 11))
+        assert vit._rt(t)["ln_fold_guard"]["off"]
+        z_g2, taps_g2 = t.forward_with_taps(x, (0, 11))
+        monkeypatch.setenv("DKD_NO_LN_FOLD", "1")
+        z_u, taps_u = t.forward_with_taps(x, (0, 11))
+    torch.cuda.synchronize()
+    for a, b in ((z_g, z_u), (z_g2, z_u), (taps_g[0], taps_u[0]), (taps_g[11], taps_u[11]), (taps_g2[11], taps_u[11])):
+        assert torch.equal(a, b)
+
+
 def test_teacher_forward_with_folded_layernorms(models, monkeypatch):
     """The whole deit_base_distilled teacher at the training batch with its LayerNorms folded into the GEMMs (24 of 25 LayerNorm launches
     gone) against the same forward with the separate LayerNorm kernels (DKD_NO_LN_FOLD=1): logits and the taps of blocks 0, 1, 11.  Both

@@ -470,6 +470,15 @@ def test_topk_correct_is_timm_accuracy(ops, C):
     for k, a in zip((1, 5), got):
         ref = correct[:min(k, C)].reshape(-1).float().sum(0) * 100. / B
         assert abs(a.item() - ref.item()) < 1e-4, (k, a.item(), ref.item())
+    # labels outside [0, C) (ignore_index -100 / -1, a class the head lacks): counted wrong, like timm -- not read out of bounds
+    lab3 = lab.clone()
+    lab3[0], lab3[1], lab3[2] = -100, -1, C
+    got = accuracy(z2, lab3, topk=(1, 5))
+    ok = torch.ones(B, dtype=torch.bool, device=z2.device)
+    ok[:3] = False
+    for k, a in zip((1, 5), got):
+        ref = (correct[:min(k, C)].any(0) & ok).float().sum() * 100. / B
+        assert abs(a.item() - ref.item()) < 1e-4, (k, a.item(), ref.item())
 
 
 def test_mse_and_mask(ops):

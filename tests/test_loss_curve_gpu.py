@@ -29,9 +29,20 @@ class Recorder:
         return loss
 
 
-@pytest.mark.parametrize("kind,width", [("mgd", 64), ("lrkd", 64), ("mgd", 192)])
-def test_loss_curve_tracks_the_oracle_loop_over_120_steps(kind, width):
-    """Asserted (the measured values are in the assertion messages / printed):
+CASES = [  # kind, student width (0 = the real architectures), epochs, batches per epoch, window
+    pytest.param("mgd", 64, 3, 20, 10, id="mgd-64-60steps"),
+    pytest.param("lrkd", 64, 3, 20, 10, id="lrkd-64-60steps"),
+    pytest.param("mgd", 192, 4, 30, 10, id="mgd-192-120steps"),
+    # BASELINE config 2 at its real width: deit_tiny_distilled <- deit_small_distilled, soft, 224 x 224, 1000 classes, through the fused
+    # D = 192 kernels; 3 epochs x 10 batches of 8 = 30 free-running steps (tools/train.py:318-334).  `-m "gpu and not real_curve"` skips it.
+    pytest.param("soft", 0, 3, 10, 10, id="soft-real-30steps", marks=pytest.mark.real_curve),
+]
+
+
+@pytest.mark.parametrize("kind,width,epochs,n_batches,win", CASES)
+def test_loss_curve_tracks_the_oracle_loop(kind, width, epochs, n_batches, win):
+    """(60 steps for the 64-wide pairs -- round 3 ran 120 on all three: the suite's time went there --, 120 for the 192-wide student
+    that takes the fused kernels, 30 for the real architectures.)  Asserted (the measured values are in the assertion messages / printed):
       * the loss averaged over windows of 10 steps, at all 12 windows: product within 0.5 % of the oracle's (measured: 0.05 %);
       * the curves are curves: the oracle's last window is well below its first (the toy problem is learning, so an all-constant
         loss could not pass), and the product's per-epoch ``train_loss`` (what train_one_epoch returns) follows the oracle's to 0.5 %;
@@ -52,15 +63,22 @@ def test_loss_curve_tracks_the_oracle_loop_over_120_steps(kind, width):
     from deltakd_amd.optim import CosineLRScheduler, create_optimizer, param_groups_weight_decay
     from deltakd_amd.shims import Mixup, NativeScaler
     torch.manual_seed(21)
-    C, B, n_batches, epochs, depth, size = 10, 8, 30, 4, 12, 32
-    args = loss_ref.default_args(distillation_type=kind, dataset="cifar-10", mgd_alpha=2.0, mgd_mask_ratio=0.5, alpha=0.5, tau=3.0,
-                                 lrkd_rank=16, opt="adamw", lr=1e-3 if width == 64 else 3e-4, weight_decay=0.05, opt_eps=1e-8, opt_betas=None, mixup=0.8, cutmix=1.0,
-                                 smoothing=0.1, epochs=epochs, print_freq=100000, rank=1)
-    o_t = vit_ref.VisionTransformerRef(128, depth, 2, C, True, 0.0, **TOY).eval()
-    heads = width // 64
-    o_s = vit_ref.VisionTransformerRef(width, depth, heads, C, False, 0.1, **TOY).train()
-    t = vit.VisionTransformer(128, depth, 2, C, True, 0.0, **TOY)
-    s = vit.VisionTransformer(width, depth, heads, C, False, 0.1, **TOY)
+    real = width == 0
+    C, B, depth, size = (1000, 8, 12, 224) if real else (10, 8, 12, 32)
+    args = loss_ref.default_args(distillation_type=kind, dataset="imagenet-1k" if real else "cifar-10", mgd_alpha=2.0, mgd_mask_ratio=0.5,
+                                 alpha=0.5, tau=3.0, lrkd_rank=16, opt="adamw", lr=1e-3 if width == 64 else 3e-4, weight_decay=0.05,
+                                 opt_eps=1e-8, opt_betas=None, mixup=0.8, cutmix=1.0, smoothing=0.1, epochs=epochs, print_freq=100000, rank=1)
+    if real:
+        t_name, s_name = "deit_small_distilled_patch16_224", "deit_tiny_distilled_patch16_224"
+        o_t = vit_ref.create_model_ref(t_name, C, 0.0).eval()
+        o_s = vit_ref.create_model_ref(s_name, C, 0.1).train()
+        t, s = vit.create_model(t_name, num_classes=C, drop_path_rate=0.0), vit.create_model(s_name, num_classes=C, drop_path_rate=0.1)
+    else:
+        o_t = vit_ref.VisionTransformerRef(128, depth, 2, C, True, 0.0, **TOY).eval()
+        heads = width // 64
+        o_s = vit_ref.VisionTransformerRef(width, depth, heads, C, False, 0.1, **TOY).train()
+        t = vit.VisionTransformer(128, depth, 2, C, True, 0.0, **TOY)
+        s = vit.VisionTransformer(width, depth, heads, C, False, 0.1, **TOY)
     loss_ref.attach_aux_ref(o_s, o_t, kind, args.lrkd_rank)
     attach_aux(s, t, kind, args)
     with torch.no_grad():
@@ -76,14 +94,16 @@ def test_loss_curve_tracks_the_oracle_loop_over_120_steps(kind, width):
 
     # a small fixed dataset with structure (class-dependent mean pattern + noise), revisited every epoch
     g = torch.Generator().manual_seed(5)
-    proto = torch.randn(C, 3, size, size, generator=g)
-    labels = [torch.randint(0, C, (B,), generator=g) for _ in range(n_batches)]
+    n_cls = min(C, 16)                      # (the real case uses 16 of its 1000 classes: a 1000-prototype table would be 600 MB)
+    n_held = 16 if real else 64
+    proto = torch.randn(n_cls, 3, size, size, generator=g)
+    labels = [torch.randint(0, n_cls, (B,), generator=g) for _ in range(n_batches)]
     data = [(0.7 * proto[y] + torch.randn(B, 3, size, size, generator=g), y) for y in labels]
-    held_y = torch.randint(0, C, (64,), generator=g)
-    held_x = 0.7 * proto[held_y] + torch.randn(64, 3, size, size, generator=g)
+    held_y = torch.randint(0, n_cls, (n_held,), generator=g)
+    held_x = 0.7 * proto[held_y] + torch.randn(n_held, 3, size, size, generator=g)
     n_steps = epochs * n_batches
     keeps = [[(torch.rand(B, generator=g) > 0.1).float() for _ in range(2 * depth)] for _ in range(n_steps)]
-    noises = [torch.rand(B, (size // 8) ** 2, generator=g) for _ in range(n_steps)]
+    noises = [torch.rand(B, (size // (16 if real else 8)) ** 2, generator=g) for _ in range(n_steps)]
     sched_kw = dict(t_initial=epochs, lr_min=1e-5, warmup_t=1, warmup_lr_init=2e-4 if width == 64 else 1e-4)
     o_mix = engine_ref.MixupRef(mixup_alpha=0.8, cutmix_alpha=1.0, label_smoothing=0.1, num_classes=C)
 
@@ -132,14 +152,13 @@ def test_loss_curve_tracks_the_oracle_loop_over_120_steps(kind, width):
     h_curve = [float(v) for v in rec.losses]
     assert len(h_curve) == len(o_curve) == n_steps
 
-    win = 10
     o_w = np.array(o_curve).reshape(-1, win).mean(1)
     h_w = np.array(h_curve).reshape(-1, win).mean(1)
     rel = np.abs(h_w - o_w) / o_w
     msg = (f"window-averaged loss  oracle {np.round(o_w, 4).tolist()}  product {np.round(h_w, 4).tolist()}  rel {np.round(rel, 4).tolist()}; "
            f"per-epoch oracle {[round(e['train_loss'], 4) for e in o_epochs]} product {[round(e['train_loss'], 4) for e in h_epochs]}")
     print(msg)
-    assert o_w[-1] < 0.9 * o_w[0], "the toy problem should be learning: " + msg
+    assert o_w[-1] < (0.97 if real else 0.9) * o_w[0], "the problem should be learning: " + msg
     assert rel.max() <= 5e-3, msg
     for he, oe in zip(h_epochs, o_epochs):
         assert abs(he["train_loss"] - oe["train_loss"]) <= 5e-3 * abs(oe["train_loss"]), msg

@@ -340,6 +340,7 @@ class DistillationLoss(nn.Module):
         # base already carries its (1 - alpha) and distill its alpha / 5.0 / ... weight (model/loss.py:226,241)
         self.last_base_loss = None
         self.last_distill_loss = None
+        self._fwt_takes_head = None  # does the teacher's forward_with_taps take ``head=``?  (looked up on first use)
 
     def _draw(self, key):
         v = self.injected.get(key)

@@ -153,9 +153,14 @@ extern "C" int dkd_block_bwd(const DkdBlock* bp, const DkdBlockGrads* gp, void* 
     // ---- attention branch
     TRY(dkd_scale_cast_bf16(r.g, D, ID, b.s1, b.N, nullptr, 1, 0, dFa, D, M, D, st));
   }
-  g = mk(dFa, b.proj_wt, r.dT, M, D, D);
-  TRY(dkd_gemm_nt(&g, st));
-  TRY(dkd_attn_bwd(b.qkv, b.o, r.dT, b.lse, r.dqkv, b.B, b.N, b.H, st));
+  if (b.fuse_attn && D == 192 && b.H == 3 && b.N >= 8 && b.N <= 208 && getenv("DKD_NO_ATTN_BWD_FUSION") == nullptr) {
+    // proj dgrad + attention backward in one launch: dO is computed head by head into the LDS image the attention backward reads
+    TRY(dkd_attn192_bwd(dFa, b.proj_wt, b.qkv, b.o, b.lse, r.dqkv, b.B, b.N, st));
+  } else {
+    g = mk(dFa, b.proj_wt, r.dT, M, D, D);
+    TRY(dkd_gemm_nt(&g, st));
+    TRY(dkd_attn_bwd(b.qkv, b.o, r.dT, b.lse, r.dqkv, b.B, b.N, b.H, st));
+  }
   if (all4 && r.defer_wgrad) {
     // the caller launches dkd_gemm_tn_group({dF, h}, {dH, y2}, {dF2, o}, {dqkv, y1}) itself
   } else if (all4) {

@@ -341,6 +341,11 @@ class DistillationLoss(nn.Module):
         self.last_base_loss = None
         self.last_distill_loss = None
         self._fwt_takes_head = None  # does the teacher's forward_with_taps take ``head=``?  (looked up on first use)
+        # The lrkd target chain (Gram matrices, one subspace-tracking step whose 96 x 96 stage is ONE workgroup per layer for 0.6-1.2 ms,
+        # projections) runs on a stream of its own behind the teacher forward: on the teacher stream the NEXT batch's forward queued
+        # behind that 3-CU kernel with 253 CUs idle.  DKD_LRKD_STREAM=0 keeps it on the teacher stream (A/B).
+        self.lrkd_stream = None
+        self._tail_stream = None     # the stream whose work finishes a run_teacher() call (the teacher stream, or lrkd_stream)
 
     def _draw(self, key):
         v = self.injected.get(key)
@@ -387,16 +392,36 @@ class DistillationLoss(nn.Module):
             logits, taps = fwt(inputs, self._TAPS.get(kind))
         pt = getattr(_unwrap(t), "num_prefix_tokens", 2)
         want_tgt = kind == "lrkd" and "lrkd_targets" not in self.injected
+        self._tail_stream = None
         if sizes is None:
-            tgt = self.lowrank([taps[0], taps[1], taps[11]], pt, lrkd_rank) if want_tgt else None
+            tgt = self._lowrank_behind(taps, [taps[0], taps[1], taps[11]], pt, lrkd_rank) if want_tgt else None
             return logits, taps, tgt
         out, lo = [], 0
         for z, n in zip(torch.split(logits, sizes) if logits is not None else [None] * len(sizes), sizes):
             part = [None if tp is None else tp[lo:lo + n] for tp in taps]          # contiguous [n, N, D] slices of [sum, N, D]
-            tgt = self.lowrank([part[0], part[1], part[11]], pt, lrkd_rank) if want_tgt else None
+            tgt = self._lowrank_behind(taps, [part[0], part[1], part[11]], pt, lrkd_rank) if want_tgt else None
             out.append((z, part, tgt))
             lo += n
         return out
+
+    def _lowrank_behind(self, owners, taps, npre, rank):
+        """The low-rank targets of one batch, on ``lrkd_stream`` when run_teacher() is executing on the teacher stream (see __init__):
+        the chain waits for the taps, the caller's completion event is then recorded on that stream (``_tail_stream``)."""
+        cur = torch.cuda.current_stream()
+        on_side = self.teacher_stream is not None and cur.cuda_stream == self.teacher_stream.cuda_stream
+        if not on_side or os.environ.get("DKD_LRKD_STREAM", "1") == "0":
+            return self.lowrank(taps, npre, rank)
+        if self.lrkd_stream is None:
+            self.lrkd_stream = torch.cuda.Stream(device=taps[0].device)
+        ls = self.lrkd_stream
+        ls.wait_stream(cur)
+        with torch.cuda.stream(ls):
+            tgt = self.lowrank(taps, npre, rank)
+        for tp in owners:                               # (allocated on the teacher stream, read on this one)
+            if tp is not None:
+                tp.record_stream(ls)
+        self._tail_stream = ls
+        return tgt
 
     def prefetch(self, inputs, args):
         """Start the teacher's work ahead of the student's (deltakd_amd.engine calls this between the loss and the backward of a
@@ -411,6 +436,8 @@ class DistillationLoss(nn.Module):
             return
         st = self.teacher_stream
         st.wait_stream(torch.cuda.current_stream())     # the batches (mixup) are ready; earlier losses have read their targets
+        if self.lrkd_stream is not None:
+            self.lrkd_stream.wait_stream(torch.cuda.current_stream())    # (its allocations are reused in stream order as well)
         rank = getattr(args, "lrkd_rank", 0)
         with torch.cuda.stream(st):
             if len(group) == 1:
@@ -418,7 +445,7 @@ class DistillationLoss(nn.Module):
             else:
                 res = self.run_teacher(torch.cat(group, 0), kind, rank, sizes=[x.shape[0] for x in group])
             ev = torch.cuda.Event()
-            ev.record(st)
+            ev.record(self._tail_stream or st)          # (the lrkd chain's stream waited for the teacher stream: its event covers both)
         for x, r in zip(group, res):
             self._ahead[id(x)] = (x, kind, r, ev)
 
@@ -466,6 +493,8 @@ class DistillationLoss(nn.Module):
             with torch.cuda.stream(self.teacher_stream):
                 t_logits, t_taps, lrkd_tgt = self.run_teacher(inputs, kind, rank)
             torch.cuda.current_stream().wait_stream(self.teacher_stream)
+            if self._tail_stream is not None:
+                torch.cuda.current_stream().wait_stream(self._tail_stream)
         else:
             t_logits, t_taps, lrkd_tgt = self.run_teacher(inputs, kind, rank)
 

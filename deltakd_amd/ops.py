@@ -157,6 +157,16 @@ def attn192_fwd(y1, wqkv, bqkv, B, N, need_lse=True):
     return qkv, out, lse
 
 
+def attn192_bwd(dy, proj_wt, qkv, out, lse, B, N):
+    """dy bf16 [B*N, 192] (gradient w.r.t. proj's output), proj_wt bf16 [192, 192] = proj.weight^T, qkv / out / lse as attn192_fwd returned
+    them -> dqkv bf16 [B*N, 576]: proj dgrad + attention backward in one launch (dO never leaves the chip)."""
+    assert dy.dtype == BF16 and dy.is_contiguous() and proj_wt.dtype == BF16 and proj_wt.is_contiguous() and proj_wt.shape == (192, 192)
+    assert qkv.dtype == BF16 and qkv.is_contiguous() and out.dtype == BF16 and out.is_contiguous() and lse.dtype == F32
+    dqkv = torch.empty(B * N, 576, device=dy.device, dtype=BF16)
+    check(lib().dkd_attn192_bwd(ptr(dy), ptr(proj_wt), ptr(qkv), ptr(out), ptr(lse), ptr(dqkv), B, N, stream()), "attn192_bwd")
+    return dqkv
+
+
 def attn_bwd(qkv, out, dout, lse, B, N, H):
     assert dout.dtype == BF16 and dout.is_contiguous() and out.is_contiguous() and qkv.is_contiguous()
     dqkv = torch.empty_like(qkv)

@@ -67,3 +67,50 @@ def test_attn192_refuses_what_it_does_not_take(ops):
     o = torch.empty(209, 192, device=dev(), dtype=BF16)
     rc = ffi.lib().dkd_attn192_fwd(ffi.ptr(y1), ffi.ptr(w), ffi.ptr(b), ffi.ptr(qkv), ffi.ptr(o), None, 1, 209, ffi.stream())
     assert rc != 0 and b"208" in ffi.lib().dkd_last_error()
+
+
+@pytest.mark.parametrize("B,N", [(2, 17), (3, 65), (5, 197), (4, 198), (3, 208), (2, 16), (300, 197), (2, 8)])
+def test_attn192_bwd(ops, B, N):
+    """proj dgrad + attention backward in one launch (csrc/attn192_bwd.hip, dkd_attn192_bwd) against fp32 torch autograd through
+    o = softmax(q k^T / 8) v, y = o Wproj^T on the kernel's own saved (bf16) q, k, v, and against the two launches it replaces
+    (dkd_gemm_nt(dy, proj_wt) -> bf16 dO -> dkd_attn_bwd).  dq / dk / dv are compared per part, relative to the part's largest element:
+    3e-2 against fp32 (bf16 operands: q, k, v, P, dS, dO all rounded), 2e-2 against the unfused launches (which round dO to bf16 in
+    memory; here it is rounded once on its way into LDS -- the same rounding -- so the two differ by summation order only).  Shapes as
+    in the forward test: B = 300 runs the persistent loop over samples; N = 208 fills the last tile; N = 8 / 16 / 17 are mostly padding."""
+    H, D = 3, 192
+    y1 = rnd(B * N, D, seed=1).to(BF16)
+    w = rnd(3 * D, D, scale=D ** -0.5, seed=2).to(BF16)
+    bias = rnd(3 * D, scale=0.5, seed=3)
+    wp = rnd(D, D, scale=D ** -0.5, seed=4).to(BF16)                 # proj.weight [out, in]
+    wpt = wp.t().contiguous()                                        # what the dgrad reads: proj.weight^T
+    dy = rnd(B * N, D, seed=5).to(BF16)
+    qkv, out, lse = ops.attn192_fwd(y1, w, bias, B, N)
+    got = ops.attn192_bwd(dy, wpt, qkv, out, lse, B, N)
+    torch.cuda.synchronize()
+    # fp32 autograd on the saved bf16 q, k, v
+    qkv32 = qkv.float().clone().requires_grad_(True)
+    q, k, v = qkv32.view(B, N, 3, H, 64).permute(2, 0, 3, 1, 4)
+    o32 = ((q @ k.transpose(-1, -2)) * 0.125).softmax(-1) @ v
+    yy = o32.transpose(1, 2).reshape(B * N, D) @ wp.float().t()
+    yy.backward(dy.float())
+    ref = qkv32.grad
+    for part, name in enumerate(("dq", "dk", "dv")):
+        close(got[:, part * D:(part + 1) * D], ref[:, part * D:(part + 1) * D], 3e-2, f"{name} vs fp32 autograd")
+    # the launches it replaces
+    d_o = ops.gemm_nt(dy, wpt)
+    unf = ops.attn_bwd(qkv, out, d_o, lse.view(B, H, N), B, N, H)
+    for part, name in enumerate(("dq", "dk", "dv")):
+        close(got[:, part * D:(part + 1) * D], unf[:, part * D:(part + 1) * D], 2e-2, f"{name} vs proj dgrad + attention backward launches")
+    # linearity in dy: twice the upstream gradient, twice the result (exact in bf16: a power of two)
+    got2 = ops.attn192_bwd((dy.float() * 2).to(BF16), wpt, qkv, out, lse, B, N)
+    assert torch.equal(got2.float(), got.float() * 2)
+
+
+def test_attn192_bwd_refuses_what_it_does_not_take(ops):
+    from deltakd_amd import ffi
+    t = torch.zeros(209 * 576, device=dev(), dtype=BF16)
+    lse = torch.zeros(3 * 209, device=dev())
+    rc = ffi.lib().dkd_attn192_bwd(ffi.ptr(t), ffi.ptr(t), ffi.ptr(t), ffi.ptr(t), ffi.ptr(lse), ffi.ptr(t), 1, 209, ffi.stream())
+    assert rc != 0 and b"208" in ffi.lib().dkd_last_error()
+    rc = ffi.lib().dkd_attn192_bwd(ffi.ptr(t), ffi.ptr(t), ffi.ptr(t), ffi.ptr(t), ffi.ptr(lse), ffi.ptr(t), 1, 4, ffi.stream())
+    assert rc != 0

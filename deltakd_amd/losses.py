@@ -154,6 +154,12 @@ class LowRankTargets:
     """
     BLOCK = 96
 
+    # "converge every batch": the setting that stands for the reference's exact per-batch svd (model/loss.py:318-326) -- 8 subspace-
+    # iteration steps from the previous batch's basis and a converged Rayleigh-Ritz step (12 Jacobi sweeps) per call instead of ONE
+    # tracking step with <= 2 sweeps.  Selected by ``--lrkd-exact`` (tools/train.py) / DKD_LRKD_EXACT=1; what it reproduces and what the
+    # default tracker gives up against it: tests/test_fullsize_gpu.py::test_lowrank_converge_every_batch_is_the_reference_exact_mode.
+    EXACT = dict(warm_iters=8, ritz_sweeps=12)
+
     def __init__(self, cold_iters=None, warm_iters=None, sweeps=12, ritz_sweeps=None, monitor_every=None, monitor_bound=None):
         """Defaults: 16 cold power steps, ONE tracking step per batch, at most 2 Jacobi sweeps inside it (what the parity tests pin:
         tests/test_fullsize_gpu.py::test_lowrank_tracking_at_the_headline_batch).  Overridable per run without touching code:
@@ -163,8 +169,9 @@ class LowRankTargets:
         sync) and, above ``monitor_bound`` (DKD_LRKD_MONITOR_BOUND, default 0.05), re-converges the basis (mode 3 + power steps)."""
         env = os.environ.get
         self.cold_iters = int(env("DKD_LRKD_COLD_ITERS", 16)) if cold_iters is None else cold_iters
-        self.warm_iters = int(env("DKD_LRKD_WARM_ITERS", 1)) if warm_iters is None else warm_iters
-        self.ritz_sweeps = int(env("DKD_LRKD_RITZ_SWEEPS", 2)) if ritz_sweeps is None else ritz_sweeps
+        exact = env("DKD_LRKD_EXACT", "0") not in ("0", "")
+        self.warm_iters = int(env("DKD_LRKD_WARM_ITERS", self.EXACT["warm_iters"] if exact else 1)) if warm_iters is None else warm_iters
+        self.ritz_sweeps = int(env("DKD_LRKD_RITZ_SWEEPS", self.EXACT["ritz_sweeps"] if exact else 2)) if ritz_sweeps is None else ritz_sweeps
         self.monitor_every = int(env("DKD_LRKD_MONITOR", 0)) if monitor_every is None else monitor_every
         self.monitor_bound = float(env("DKD_LRKD_MONITOR_BOUND", 0.05)) if monitor_bound is None else monitor_bound
         self.sweeps = sweeps
@@ -480,8 +487,10 @@ class DistillationLoss(nn.Module):
             raise ValueError(f"Invalid distillation type: {self.distillation_type}")
 
         rank = getattr(args, "lrkd_rank", 0)
-        for knob in ("warm_iters", "ritz_sweeps"):                 # --lrkd-warm-iters / --lrkd-ritz-sweeps (tools/train.py)
+        for knob in ("warm_iters", "ritz_sweeps"):                 # --lrkd-warm-iters / --lrkd-ritz-sweeps / --lrkd-exact (tools/train.py)
             v = getattr(args, "lrkd_" + knob, None)
+            if v is None and getattr(args, "lrkd_exact", False):
+                v = LowRankTargets.EXACT[knob]
             if v is not None:
                 setattr(self.lowrank, knob, int(v))
         ahead = self._ahead.pop(id(inputs), None)

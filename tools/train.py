@@ -59,6 +59,9 @@ def parse_args(argv=None):
     for flag, ty, default in typed:
         p.add_argument(flag, type=ty, default=default)
     p.add_argument("--dr", dest="decay_rate", type=F)
+    # not in the reference either: converge the LRKD subspace on EVERY batch (= --lrkd-warm-iters 8 --lrkd-ritz-sweeps 12), the setting
+    # that stands for the reference's exact per-batch svd (model/loss.py:318-326); the default tracks the subspace from batch to batch
+    p.add_argument("--lrkd-exact", action="store_true")
     for flag in ("--fp16", "--amp", "--wandb", "--resplit", "--ThreeAugment", "--src", "--resume", "--finetune"):
         p.add_argument(flag, action="store_true")
     p.add_argument("--pin-mem", action="store_true", default=True)

@@ -31,7 +31,12 @@ constexpr int G_IMG = G_ROWS * 128;                                   // one ima
 constexpr int G_Q = 0, G_K = G_IMG, G_V = 2 * G_IMG, G_DO = 3 * G_IMG;
 constexpr int G_W = 4 * G_IMG, G_W_BYTES = 64 * 384;                  // the head's 64 rows of proj.weight^T: 64 x 192 bf16
 constexpr int G_LSE = G_W + G_W_BYTES, G_NDL = G_LSE + G_ROWS * 4;    // lse log2(e) and -rowsum(dO o O) / 8 per row
-constexpr int G_SMEM = G_NDL + G_ROWS * 4;                            // 141 056 B
+constexpr int G_HEADS_END = G_NDL + G_ROWS * 4;                       // 141 056 B: what the head loop uses
+// phase C (qkv dgrad + LayerNorm backward) reuses the images' space: two buffers for a third of qkv.weight^T each ([192 rows, 192 k] bf16)
+constexpr int G_CBUF = 192 * 384;                                     // 73 728 B
+constexpr int G_RED = 2 * G_CBUF;                                     // f32 [2][192]: this workgroup's partial dgamma | dbeta
+constexpr int G_SMEM = G_RED + 2 * G_D * 4;                           // 148 992 B
+static_assert(G_RED >= G_HEADS_END, "the partial sums must survive the head loops of later samples");
 constexpr float G_LOG2E = 1.4426950408889634f;
 
 // Dev-only ablation bits (build with -DDKD_ATTN192B_ABL=n; results are then wrong, timings are the point): 1 no phase P MFMAs,
@@ -48,6 +53,14 @@ struct Attn192Bwd {
   const bf16_t* o;        // bf16 [B * N, 192] saved by the forward
   const float* lse;       // f32 [B, 3, N]
   bf16_t* dqkv;           // bf16 [B * N, 576] out
+  // phase C, optional (wqt == NULL: the kernel stops at dqkv)
+  const bf16_t* wqt;      // bf16 [192, 576]: qkv.weight^T (row i = input feature i)
+  const float* x;         // f32 [B * N, 192]: the block's input (what norm1 normalised)
+  const float* gamma;     // f32 [192]: norm1.weight
+  const float* mean;      // f32 [B * N]
+  const float* rstd;      // f32 [B * N]
+  float* g;               // f32 [B * N, 192]: gradient stream, += LN'(dqkv Wqkv)
+  float* part;            // f32 [gridDim.x][384]: this workgroup's partial dgamma | dbeta (summed by dkd_ln_bwd_reduce)
   int B, N;
 };
 
@@ -112,6 +125,198 @@ __device__ __forceinline__ void g_dma16(uint32_t lds_dst, const void* src) {    
 #pragma clang diagnostic pop
 }
 
+// sum over the 16 lanes of a DPP row (lanes 16 k .. 16 k + 15), result in every lane of the row: two quad permutes, two row rotations
+__device__ __forceinline__ float g_row_sum16(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false));    // quad_perm [1,0,3,2]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, false));    // quad_perm [2,3,0,1]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xF, 0xF, false));   // row_ror:4
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xF, 0xF, false));   // row_ror:8
+  return v;
+}
+
+// Phase C of attn192_bwd_kernel as a function of its own (NOT inlined: its 96 accumulator + 48 operand registers would otherwise be
+// allocated together with the head loop's and spill there; what is live across the call is a handful of scalars).
+__device__ __forceinline__ const bf16_t* g_uniform_ptr(const bf16_t* q) {      // a wave-uniform pointer the compiler can keep in SGPRs
+  const uint64_t v = (uint64_t)(uintptr_t)q;
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+  return (const bf16_t*)(uintptr_t)(((uint64_t)hi << 32) | lo);
+}
+__device__ __noinline__ void attn192_bwd_phase_c(const Attn192Bwd p, char* smem, const size_t row0, const int lane, const int w_in) {
+  const int w = __builtin_amdgcn_readfirstlane(w_in);
+  const bf16_t* wqt = g_uniform_ptr(p.wqt);
+  const int N = p.N, nt = (N + 15) >> 4;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)LDS_PTR(smem);
+  float* red = (float*)(smem + G_RED);
+  const int grp[2] = {w, w + 8};
+  const int ng = (grp[0] < nt ? 1 : 0) + (grp[1] < nt ? 1 : 0);
+  // ================= C: dT^T [192 features, 16 rows] per group = Wqkv^T [192, 576] dqkv^T, then the LayerNorm backward on whole rows.
+  // qkv.weight^T streams through two LDS buffers in three K chunks (the q, k and v thirds of the 576), rows permuted like the other
+  // weight images (a lane's accumulators of tiles 2 j, 2 j + 1 = 8 consecutive features of ONE row); the B operand is the group's own
+  // dqkv rows, read back from L2 (this CU has just written them: the stores were drained above, the lines were never in its L1).
+  {
+    // (the lane index goes through an opaque asm: everything derived from it below is computed HERE, not hoisted out of the sample loop into
+    // registers that would have to live -- spilled -- across the head loop)
+    int lane_c = lane;
+    asm volatile("" : "+v"(lane_c));
+    const int i16 = lane_c & 15, fg = lane_c >> 4, ax = (i16 >> 1) & 7;
+    uint32_t csrc[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      const int o = (9 * w + k) * 1024 + lane_c * 16;
+      const int row = o / 384, cb = o % 384;
+      const int ps = cb >> 4;
+      const int ls = (ps & ~7) | ((ps & 7) ^ ((row >> 1) & 7));
+      const int t = row >> 4, rho = row & 15;
+      const int feat = 32 * (t >> 1) + 8 * (rho >> 2) + 4 * (t & 1) + (rho & 3);
+      csrc[k] = (uint32_t)((feat * (3 * G_D) + ls * 8) * 2);         // byte offset inside qkv.weight^T for chunk 0
+    }
+    auto load_chunk = [&](const int ch, const int buf) {
+#pragma unroll
+      for (int k = 0; k < 9; ++k) {
+        const uint32_t dst = __builtin_amdgcn_readfirstlane(lds0 + buf * G_CBUF + (9 * w + k) * 1024);
+        const uint32_t voff = csrc[k] + (uint32_t)ch * (G_D * 2);
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(dst), "v"(voff), "s"(wqt) : "memory", "m0");
+#pragma clang diagnostic pop
+      }
+    };
+    const bf16_t* brow[2];
+    bool blive[2];
+#pragma unroll
+    for (int rg = 0; rg < 2; ++rg) {
+      const int r = grp[rg] * 16 + i16;
+      blive[rg] = rg < ng && r < N;
+      brow[rg] = p.dqkv + (row0 + (blive[rg] ? r : 0)) * (3 * G_D) + 8 * fg;
+    }
+    gu32x4 bq[2][6];
+    auto load_b = [&](const int ch, auto kkc) {                      // the two groups' B fragments of K step kk of chunk ch
+      constexpr int kk = decltype(kkc)::value;
+#pragma unroll
+      for (int rg = 0; rg < 2; ++rg) g_issue_gload(brow[rg] + ch * G_D + 32 * kk, bq[rg][kk]);
+    };
+    load_chunk(0, 0);
+    g_static_for<6>([&](auto kkc) { load_b(0, kkc); });
+    load_chunk(1, 1);
+
+    auto phase_c = [&](auto ngc) {
+      constexpr int NG = decltype(ngc)::value;
+      f32x4 acc[NG][12];
+#pragma unroll
+      for (int rg = 0; rg < NG; ++rg)
+#pragma unroll
+        for (int dt = 0; dt < 12; ++dt) acc[rg][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ch = 0; ch < 3; ++ch) {
+        const int buf = ch & 1;
+        // chunk ch and its B fragments have landed: everything but the 9 pieces of the chunk issued after them (none after the last)
+        if (ch < 2) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const uint32_t c0 = lds0 + buf * G_CBUF + i16 * 384 + 16 * (fg ^ ax), c1 = lds0 + buf * G_CBUF + i16 * 384 + 16 * ((4 | fg) ^ ax);
+        const uint32_t c0h = c0 + 6 * (16 * 384), c1h = c1 + 6 * (16 * 384);
+#pragma unroll
+        for (int rg = 0; rg < NG; ++rg)
+#pragma unroll
+          for (int kk = 0; kk < 6; ++kk) {
+            asm volatile("" : "+v"(bq[rg][kk]));                     // (released by the counted wait above)
+            if (!blive[rg]) bq[rg][kk] = gu32x4{0u, 0u, 0u, 0u};     // padded rows: dT = 0 (nothing for dgamma / dbeta, no dx stored)
+          }
+        gu32x4 fr[4];
+        auto issue = [&](auto ii) {                                  // fragment ii: K step ii / 12, feature tile ii % 12
+          constexpr int i = decltype(ii)::value, kk = i / 12, dt = i % 12;
+          g_issue_row<(dt % 6) * (16 * 384) + (kk >> 1) * 128>(dt < 6 ? ((kk & 1) ? c1 : c0) : ((kk & 1) ? c1h : c0h), fr[i & 3]);
+        };
+        g_static_for<4>(issue);
+        g_static_for<72>([&](auto ii) {
+          constexpr int i = decltype(ii)::value, kk = i / 12, dt = i % 12;
+          g_wait<(71 - i < 3 ? 71 - i : 3)>(fr[i & 3]);
+#pragma unroll
+          for (int rg = 0; rg < NG; ++rg) acc[rg][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(g_bf(fr[i & 3]), g_bf(bq[rg][kk]), acc[rg][dt], 0, 0, 0);
+          if constexpr (i + 4 < 72) issue(std::integral_constant<int, i + 4>{});
+          // K step kk is done: its registers take the next chunk's fragments (an MFMA reads its operands at issue, long before the load returns)
+          if constexpr (dt == 11)
+            if (ch < 2) load_b(ch + 1, std::integral_constant<int, kk>{});
+        });
+        if (ch < 2) {
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_s_barrier();                              // everybody is done reading this buffer
+          if (ch == 0) load_chunk(2, 0);
+        }
+      }
+      // ---- LayerNorm backward on the wave's rows: dx = rstd (dT gamma - mean(dT gamma) - xhat mean(dT gamma xhat)), g += dx; a lane holds
+      // features 32 j + 8 fg .. + 7 (j = 0..5) of row i16 in tiles 2 j, 2 j + 1; the row's other features sit in the lanes i16 + 16 k
+#pragma unroll
+      for (int rg = 0; rg < NG; ++rg) {
+        asm volatile("" ::: "memory");                               // (one group at a time: the loads of the next one stay below this line)
+        const int r = grp[rg] * 16 + i16;
+        const bool live = r < N;
+        const size_t rowp = row0 + (live ? r : 0);
+        const float mu = p.mean[rowp], rs = p.rstd[rowp];
+        const float* xr = p.x + rowp * G_D + 8 * fg;
+        float* gr = p.g + rowp * G_D + 8 * fg;
+        f32x4 xh[12];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < 6; ++j)
+#pragma unroll
+          for (int hf = 0; hf < 2; ++hf) {
+            const f32x4 xv = *(const f32x4*)(xr + 32 * j + 4 * hf);
+            const f32x4 gm = *(const f32x4*)(p.gamma + 32 * j + 8 * fg + 4 * hf);
+            f32x4& d = acc[rg][2 * j + hf];
+            f32x4 pg, pb;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float xe = (xv[e] - mu) * rs;
+              xh[2 * j + hf][e] = xe;
+              pb[e] = live ? d[e] : 0.f;
+              pg[e] = pb[e] * xe;
+              d[e] *= gm[e];                                         // gy, kept in the accumulator's registers
+              s1 += d[e];
+              s2 += d[e] * xe;
+            }
+            // partial dgamma / dbeta of these 4 features: the 16 rows of the group, then this workgroup's running sums in LDS
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              pg[e] = g_row_sum16(pg[e]);
+              pb[e] = g_row_sum16(pb[e]);
+            }
+            if (i16 == 0) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                atomicAdd(&red[32 * j + 8 * fg + 4 * hf + e], pg[e]);
+                atomicAdd(&red[G_D + 32 * j + 8 * fg + 4 * hf + e], pb[e]);
+              }
+            }
+          }
+        asm volatile("" ::: "memory");
+        s1 += __shfl_xor(s1, 16, 64);
+        s1 += __shfl_xor(s1, 32, 64);
+        s2 += __shfl_xor(s2, 16, 64);
+        s2 += __shfl_xor(s2, 32, 64);
+        s1 *= 1.f / G_D;
+        s2 *= 1.f / G_D;
+        if (live && (!(GABL & 8) || p.B < 0)) {
+#pragma unroll
+          for (int j = 0; j < 6; ++j)
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+              const f32x4 gv = *(const f32x4*)(gr + 32 * j + 4 * hf);
+              const f32x4& gy = acc[rg][2 * j + hf];
+              f32x4 o;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) o[e] = fmaf(rs, gy[e] - s1 - xh[2 * j + hf][e] * s2, gv[e]);
+              *(f32x4*)(gr + 32 * j + 4 * hf) = o;
+            }
+        }
+      }
+    };
+    if (ng == 2) phase_c(std::integral_constant<int, 2>{});
+    else phase_c(std::integral_constant<int, 1>{});
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+}
+
 __global__ __launch_bounds__(512, 1) void attn192_bwd_kernel(const Attn192Bwd p) {
   __shared__ __attribute__((aligned(16))) char smem[G_SMEM];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -124,13 +329,8 @@ __global__ __launch_bounds__(512, 1) void attn192_bwd_kernel(const Attn192Bwd p)
   float* ndl_s = (float*)(smem + G_NDL);
   const float c = 0.125f * G_LOG2E;
 
-  // ---- rows neither the DMA (rows < 8 npc of q, k, v) nor phase P (rows < 16 nt of dO) ever writes stay zero for the whole kernel
-  for (int i = npc * 64 + tid; i < G_IMG / 16; i += 512) {
-    *(uint4*)(smem + G_Q + i * 16) = uint4{0u, 0u, 0u, 0u};
-    *(uint4*)(smem + G_K + i * 16) = uint4{0u, 0u, 0u, 0u};
-    *(uint4*)(smem + G_V + i * 16) = uint4{0u, 0u, 0u, 0u};
-  }
-  for (int i = nt * 128 + tid; i < G_IMG / 16; i += 512) *(uint4*)(smem + G_DO + i * 16) = uint4{0u, 0u, 0u, 0u};
+  float* red = (float*)(smem + G_RED);
+  for (int i = tid; i < 2 * G_D; i += 512) red[i] = 0.f;
 
   // ---- LDS-DMA pieces of the weight image: 24 pieces of 1 KiB per head, wave w issues pieces 3 w .. 3 w + 2
   uint32_t wsrc[3];
@@ -192,8 +392,16 @@ __global__ __launch_bounds__(512, 1) void attn192_bwd_kernel(const Attn192Bwd p)
   const int ng = (grp[0] < nt ? 1 : 0) + (grp[1] < nt ? 1 : 0);        // wave-uniform
   for (int b = blockIdx.x; b < p.B; b += gridDim.x) {
     const size_t row0 = (size_t)b * N;
-    __builtin_amdgcn_s_waitcnt(0xC07F);                                // lgkmcnt(0): zero fill (first sample)
-    __syncthreads();                                                   // (later samples: everybody is done with the previous one's images)
+    // ---- rows neither the DMA (rows < 8 npc of q, k, v) nor phase P (rows < 16 nt of dO) ever writes must read as zeros (phase C of the
+    // previous sample has used the space)
+    for (int i = npc * 64 + tid; i < G_IMG / 16; i += 512) {
+      *(uint4*)(smem + G_Q + i * 16) = uint4{0u, 0u, 0u, 0u};
+      *(uint4*)(smem + G_K + i * 16) = uint4{0u, 0u, 0u, 0u};
+      *(uint4*)(smem + G_V + i * 16) = uint4{0u, 0u, 0u, 0u};
+    }
+    for (int i = nt * 128 + tid; i < G_IMG / 16; i += 512) *(uint4*)(smem + G_DO + i * 16) = uint4{0u, 0u, 0u, 0u};
+    __builtin_amdgcn_s_waitcnt(0xC07F);                                // lgkmcnt(0)
+    __syncthreads();
     load_weights(0);
     // ---- the wave's dY rows as MFMA B operands, for all three heads (lane (row i16, k group fg): features 32 kk + 8 fg .. + 7)
     bf16x8 xt[2][6];
@@ -432,17 +640,27 @@ __global__ __launch_bounds__(512, 1) void attn192_bwd_kernel(const Attn192Bwd p)
           }
         }
       }
+      if (h + 1 == G_H && p.wqt) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // phase C reads every wave's dq / dk / dv rows back
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();                                    // everybody is done with this head's images
     }
+    if (p.wqt) attn192_bwd_phase_c(p, smem, row0, lane, w);
+  }
+  if (p.wqt) {                                                          // this workgroup's partial dgamma | dbeta
+    __syncthreads();
+    for (int i = tid; i < 2 * G_D; i += 512) p.part[(size_t)blockIdx.x * (2 * G_D) + i] = red[i];
   }
 }
 
 }  // namespace
 
-extern "C" int dkd_attn192_bwd(const void* dy, const void* proj_wt, const void* qkv, const void* o, const float* lse, void* dqkv, int32_t B,
-                               int32_t N, void* stream) {
+extern "C" int dkd_attn192_bwd(const void* dy, const void* proj_wt, const void* qkv, const void* o, const float* lse, void* dqkv,
+                               const void* qkv_wt, const float* x, const float* ln_w, const float* mean, const float* rstd, float* g,
+                               float* d_ln_w, float* d_ln_b, float* ws, int32_t B, int32_t N, void* stream) {
   DKD_CHECK_ARG(dy && proj_wt && qkv && o && lse && dqkv, "attn192_bwd: null operand");
+  DKD_CHECK_ARG(!qkv_wt || (x && ln_w && mean && rstd && g && d_ln_w && d_ln_b && ws),
+                "attn192_bwd: with qkv_wt (the qkv dgrad + LayerNorm backward) x, ln_w, mean, rstd, g, d_ln_w, d_ln_b and ws are needed");
+  DKD_CHECK_ARG(!qkv_wt || ((((uintptr_t)qkv_wt | (uintptr_t)x | (uintptr_t)ln_w | (uintptr_t)g) & 15) == 0), "attn192_bwd: operands must be 16-byte aligned");
   DKD_CHECK_ARG(B > 0 && N >= 8 && N <= 208, "attn192_bwd: need 8 <= N <= 208 tokens (N=%d)", N);
   DKD_CHECK_ARG((((uintptr_t)dy | (uintptr_t)proj_wt | (uintptr_t)qkv | (uintptr_t)o | (uintptr_t)dqkv) & 15) == 0, "attn192_bwd: operands must be 16-byte aligned");
   DKD_CHECK_ARG((long)B * N * 576 < (1L << 31), "attn192_bwd: qkv too large for 32-bit offsets");
@@ -459,8 +677,12 @@ extern "C" int dkd_attn192_bwd(const void* dy, const void* proj_wt, const void* 
   Attn192Bwd p;
   p.dy = (const bf16_t*)dy; p.wpt = (const bf16_t*)proj_wt; p.qkv = (const bf16_t*)qkv; p.o = (const bf16_t*)o; p.lse = lse;
   p.dqkv = (bf16_t*)dqkv; p.B = B; p.N = N;
+  p.wqt = (const bf16_t*)qkv_wt; p.x = x; p.gamma = ln_w; p.mean = mean; p.rstd = rstd; p.g = g; p.part = ws;
   const int grid = B < n_cu ? B : n_cu;
+  DKD_CHECK_ARG(!qkv_wt || (int64_t)grid * 2 * G_D * 4 <= dkd_layernorm_bwd_workspace_bytes(B * N, G_D),
+                "attn192_bwd: ws (dkd_layernorm_bwd_workspace_bytes) too small for %d partial rows", grid);
   hipLaunchKernelGGL(attn192_bwd_kernel, dim3(grid), dim3(512), 0, as_stream(stream), p);
   DKD_CHECK_LAUNCH("attn192_bwd");
+  if (qkv_wt) return dkd_ln_bwd_reduce(ws, grid, d_ln_w, d_ln_b, G_D, stream);
   return DKD_OK;
 }

@@ -153,9 +153,17 @@ extern "C" int dkd_block_bwd(const DkdBlock* bp, const DkdBlockGrads* gp, void* 
     // ---- attention branch
     TRY(dkd_scale_cast_bf16(r.g, D, ID, b.s1, b.N, nullptr, 1, 0, dFa, D, M, D, st));
   }
+  bool branch_done = false;             // the fused kernel has also run the qkv dgrad + norm1's backward
   if (b.fuse_attn && D == 192 && b.H == 3 && b.N >= 8 && b.N <= 208 && getenv("DKD_NO_ATTN_BWD_FUSION") == nullptr) {
-    // proj dgrad + attention backward in one launch: dO is computed head by head into the LDS image the attention backward reads
-    TRY(dkd_attn192_bwd(dFa, b.proj_wt, b.qkv, b.o, b.lse, r.dqkv, b.B, b.N, st));
+    // proj dgrad + attention backward in one launch (dO is computed head by head into the LDS image the attention backward reads) and,
+    // with the LayerNorm fusion, the qkv dgrad + norm1's backward behind them (DKD_ATTN_BWD_NO_LN=1 keeps that as its own launch: A/B)
+    branch_done = fuse_ln && getenv("DKD_ATTN_BWD_NO_LN") == nullptr;
+    if (branch_done)
+      TRY(dkd_attn192_bwd(dFa, b.proj_wt, b.qkv, b.o, b.lse, r.dqkv, b.qkv_wt, b.x, b.ln1_w, b.mean1, b.rstd1, r.g, r.d_ln1_w, r.d_ln1_b,
+                          ln_ws1, b.B, b.N, st));
+    else
+      TRY(dkd_attn192_bwd(dFa, b.proj_wt, b.qkv, b.o, b.lse, r.dqkv, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                          nullptr, b.B, b.N, st));
   } else {
     g = mk(dFa, b.proj_wt, r.dT, M, D, D);
     TRY(dkd_gemm_nt(&g, st));
@@ -174,6 +182,7 @@ extern "C" int dkd_block_bwd(const DkdBlock* bp, const DkdBlockGrads* gp, void* 
                                {r.dqkv, b.y1, r.d_qkv_w, r.d_qkv_b, M, 3 * D, D, 3 * D, D, D, ID, ID}};
     TRY(dkd_gemm_tn_group(w, 2, st));
   }
+  if (branch_done) return DKD_OK;
   if (fuse_ln) {
     TRY(dkd_gemm_nt_lnbwd(r.dqkv, b.qkv_wt, M, 3 * D, 3 * D, 3 * D, b.x, D, b.ln1_w, b.mean1, b.rstd1, r.g, D, r.d_ln1_w, r.d_ln1_b, ln_ws1,
                           nullptr, nullptr, 0, st));

@@ -157,13 +157,21 @@ def attn192_fwd(y1, wqkv, bqkv, B, N, need_lse=True):
     return qkv, out, lse
 
 
-def attn192_bwd(dy, proj_wt, qkv, out, lse, B, N):
+def attn192_bwd(dy, proj_wt, qkv, out, lse, B, N, *, qkv_wt=None, x=None, ln_w=None, mean=None, rstd=None, g=None, d_ln_w=None, d_ln_b=None):
     """dy bf16 [B*N, 192] (gradient w.r.t. proj's output), proj_wt bf16 [192, 192] = proj.weight^T, qkv / out / lse as attn192_fwd returned
-    them -> dqkv bf16 [B*N, 576]: proj dgrad + attention backward in one launch (dO never leaves the chip)."""
+    them -> dqkv bf16 [B*N, 576]: proj dgrad + attention backward in one launch (dO never leaves the chip).  With ``qkv_wt`` (bf16 [192, 576] =
+    qkv.weight^T) the same launch also runs the qkv dgrad and norm1's backward: g f32 [B*N, 192] += LN'(dqkv Wqkv), d_ln_w / d_ln_b +=."""
     assert dy.dtype == BF16 and dy.is_contiguous() and proj_wt.dtype == BF16 and proj_wt.is_contiguous() and proj_wt.shape == (192, 192)
     assert qkv.dtype == BF16 and qkv.is_contiguous() and out.dtype == BF16 and out.is_contiguous() and lse.dtype == F32
     dqkv = torch.empty(B * N, 576, device=dy.device, dtype=BF16)
-    check(lib().dkd_attn192_bwd(ptr(dy), ptr(proj_wt), ptr(qkv), ptr(out), ptr(lse), ptr(dqkv), B, N, stream()), "attn192_bwd")
+    ws = None
+    if qkv_wt is not None:
+        assert qkv_wt.dtype == BF16 and qkv_wt.is_contiguous() and qkv_wt.shape == (192, 576)
+        for t in (x, ln_w, mean, rstd, g, d_ln_w, d_ln_b):
+            assert t is not None and t.dtype == F32 and t.is_contiguous()
+        ws = torch.empty(lib().dkd_layernorm_bwd_workspace_bytes(B * N, 192) // 4, device=dy.device, dtype=F32)
+    check(lib().dkd_attn192_bwd(ptr(dy), ptr(proj_wt), ptr(qkv), ptr(out), ptr(lse), ptr(dqkv), ptr(qkv_wt), ptr(x), ptr(ln_w), ptr(mean),
+                                ptr(rstd), ptr(g), ptr(d_ln_w), ptr(d_ln_b), ptr(ws), B, N, stream()), "attn192_bwd")
     return dqkv
 
 

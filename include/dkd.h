@@ -188,13 +188,21 @@ int dkd_mlp192_fwd(const float* x1, const float* ln_w, const float* ln_b, float 
  * head, lse f32 [B, 3, N] (may be NULL).  y1 bf16 [B*N, 192] (norm1 output), wqkv bf16 [576, 192], bqkv f32 [576].  Same results as
  * dkd_gemm_nt(BIAS) + dkd_attn_fwd up to the summation order (DkdBlock.fuse_attn selects it). */
 int dkd_attn192_fwd(const void* y1, const void* wqkv, const float* bqkv, void* qkv, void* o, float* lse, int32_t B, int32_t N, void* stream);
-/* Backward of the same branch up to the qkv gradient, one launch ([3P] autograd of timm Attention.forward, reached from the reference's
- * loss_scaler call at tools/engine.py:61-62): dO = dy proj.weight (never written: each head's slice is computed into the LDS image the
- * attention backward reads), then dq, dk, dv per head into dqkv bf16 [B*N, 576].  dy bf16 [B*N, 192] (gradient w.r.t. proj's output,
- * DropPath scale applied), proj_wt bf16 [192, 192] = proj.weight^T, qkv / o / lse as dkd_attn192_fwd wrote them.  8 <= N <= 208.  Same
- * results as dkd_gemm_nt(dy, proj_wt) + dkd_attn_bwd up to one bf16 rounding of dO less (DkdBlock.fuse_attn selects it in dkd_block_bwd). */
-int dkd_attn192_bwd(const void* dy, const void* proj_wt, const void* qkv, const void* o, const float* lse, void* dqkv, int32_t B, int32_t N,
-                    void* stream);
+/* Backward of the same branch, one launch ([3P] autograd of timm Attention.forward and of the LayerNorm in front of it, reached from
+ * the reference's loss_scaler call at tools/engine.py:61-62): dO = dy proj.weight (never written: each head's slice is computed into the
+ * LDS image the attention backward reads), then dq, dk, dv per head into dqkv bf16 [B*N, 576] (the qkv weight gradient reads it).
+ * dy bf16 [B*N, 192] (gradient w.r.t. proj's output, DropPath scale applied), proj_wt bf16 [192, 192] = proj.weight^T, qkv / o / lse as
+ * dkd_attn192_fwd wrote them.  8 <= N <= 208.
+ * With qkv_wt (bf16 [192, 576] = qkv.weight^T; NULL: stop at dqkv) the kernel goes on to the branch's input: dT = dqkv qkv.weight stays
+ * on chip (f32) and  g[m,:] += LN'(dT[m,:]),  d_ln_w += sum_m dT xhat,  d_ln_b += sum_m dT  -- the arithmetic of dkd_gemm_nt_lnbwd -- with
+ * x f32 [B*N, 192] the block's input, ln_w = norm1.weight, mean / rstd f32 [B*N] norm1's saved statistics, g f32 [B*N, 192] the gradient
+ * stream, ws dkd_layernorm_bwd_workspace_bytes(B*N, 192) bytes (one partial row per workgroup, summed by the reduction launch, which
+ * dkd_block_bwd may defer: DkdBlockGrads.ln_defer).
+ * Same results as dkd_gemm_nt(dy, proj_wt) + dkd_attn_bwd (+ dkd_gemm_nt_lnbwd) up to one bf16 rounding of dO less and the summation
+ * order (DkdBlock.fuse_attn selects it in dkd_block_bwd). */
+int dkd_attn192_bwd(const void* dy, const void* proj_wt, const void* qkv, const void* o, const float* lse, void* dqkv, const void* qkv_wt,
+                    const float* x, const float* ln_w, const float* mean, const float* rstd, float* g, float* d_ln_w, float* d_ln_b,
+                    float* ws, int32_t B, int32_t N, void* stream);
 int dkd_mlp192_bwd(float* g, const void* gtap, const float* s2, const float* s1, int32_t rows_per_sample, const void* pre,
                    const void* fc2_wt, const void* fc1_w, const float* x1, const float* ln_w, const float* mean, const float* rstd, void* dF,
                    void* dH, void* cast_out, float* d_ln_w, float* d_ln_b, float* ws, int32_t M, int32_t hidden, void* stream);

@@ -106,11 +106,59 @@ def test_attn192_bwd(ops, B, N):
     assert torch.equal(got2.float(), got.float() * 2)
 
 
+@pytest.mark.parametrize("B,N", [(2, 17), (5, 197), (4, 198), (3, 208), (300, 197), (2, 8)])
+def test_attn192_bwd_with_the_layernorm_backward(ops, B, N):
+    """The same launch carried through to the branch's input (dkd_attn192_bwd with qkv_wt): dT = dqkv Wqkv stays on chip and the kernel's
+    epilogue is norm1's backward -- g += LN'(dT), d_ln_w += sum dT xhat, d_ln_b += sum dT.  Checked against fp32 torch on the kernel's own
+    (bf16) dqkv: dx to 2e-3 of the largest element (dT is an fp32 accumulation of bf16 products on both sides), the parameter gradients to
+    2e-3; and against the launch it replaces (dkd_gemm_nt_lnbwd on that dqkv): same arithmetic, other summation order.  dqkv itself must be
+    what the launch without the LayerNorm part writes (bit for bit: the head loop is the same code)."""
+    H, D = 3, 192
+    y1 = rnd(B * N, D, seed=1).to(BF16)
+    w = rnd(3 * D, D, scale=D ** -0.5, seed=2).to(BF16)                  # qkv.weight [576, 192]
+    bias = rnd(3 * D, scale=0.5, seed=3)
+    wpt = rnd(D, D, scale=D ** -0.5, seed=4).to(BF16)
+    dy = rnd(B * N, D, seed=5).to(BF16)
+    x = rnd(B * N, D, seed=6, scale=1.5) + 0.2
+    gamma = 1.0 + 0.2 * rnd(D, seed=7)
+    g0 = rnd(B * N, D, seed=8, scale=0.5)
+    mean = x.mean(1).contiguous()
+    rstd = torch.rsqrt(x.var(1, unbiased=False) + 1e-6).contiguous()
+    qkv, out, lse = ops.attn192_fwd(y1, w, bias, B, N)
+    wqt = w.t().contiguous()                                             # [192, 576] = qkv.weight^T
+    g = g0.clone()
+    dgam, dbet = torch.zeros(D, device=dev()), torch.zeros(D, device=dev())
+    dqkv = ops.attn192_bwd(dy, wpt, qkv, out, lse, B, N, qkv_wt=wqt, x=x, ln_w=gamma, mean=mean, rstd=rstd, g=g, d_ln_w=dgam, d_ln_b=dbet)
+    torch.cuda.synchronize()
+    assert torch.equal(dqkv, ops.attn192_bwd(dy, wpt, qkv, out, lse, B, N)), "dqkv must not depend on the LayerNorm part"
+    # fp32 reference on the kernel's own dqkv
+    dT = dqkv.float() @ w.float()                                        # [M, 192]
+    xh = (x - mean[:, None]) * rstd[:, None]
+    gy = dT * gamma
+    dx = rstd[:, None] * (gy - gy.mean(1, keepdim=True) - xh * (gy * xh).mean(1, keepdim=True))
+    close(g - g0, dx, 2e-3, "dx vs fp32")
+    close(dgam, (dT * xh).sum(0), 2e-3, "d_ln_w vs fp32")
+    close(dbet, dT.sum(0), 2e-3, "d_ln_b vs fp32")
+    # the launch it replaces
+    g_u = g0.clone()
+    dgam_u, dbet_u = torch.zeros(D, device=dev()), torch.zeros(D, device=dev())
+    ws = torch.empty(ops.lib().dkd_layernorm_bwd_workspace_bytes(B * N, D) // 4, device=dev())
+    ops.gemm_nt_lnbwd(dqkv, wqt, x, gamma, mean, rstd, g_u, dgam_u, dbet_u, ws)
+    torch.cuda.synchronize()
+    close(g, g_u, 1e-3, "dx vs dkd_gemm_nt_lnbwd")
+    close(dgam, dgam_u, 1e-3, "d_ln_w vs dkd_gemm_nt_lnbwd")
+    close(dbet, dbet_u, 1e-3, "d_ln_b vs dkd_gemm_nt_lnbwd")
+
+
 def test_attn192_bwd_refuses_what_it_does_not_take(ops):
     from deltakd_amd import ffi
     t = torch.zeros(209 * 576, device=dev(), dtype=BF16)
     lse = torch.zeros(3 * 209, device=dev())
-    rc = ffi.lib().dkd_attn192_bwd(ffi.ptr(t), ffi.ptr(t), ffi.ptr(t), ffi.ptr(t), ffi.ptr(lse), ffi.ptr(t), 1, 209, ffi.stream())
+    none = [None] * 9
+    rc = ffi.lib().dkd_attn192_bwd(ffi.ptr(t), ffi.ptr(t), ffi.ptr(t), ffi.ptr(t), ffi.ptr(lse), ffi.ptr(t), *none, 1, 209, ffi.stream())
     assert rc != 0 and b"208" in ffi.lib().dkd_last_error()
-    rc = ffi.lib().dkd_attn192_bwd(ffi.ptr(t), ffi.ptr(t), ffi.ptr(t), ffi.ptr(t), ffi.ptr(lse), ffi.ptr(t), 1, 4, ffi.stream())
+    rc = ffi.lib().dkd_attn192_bwd(ffi.ptr(t), ffi.ptr(t), ffi.ptr(t), ffi.ptr(t), ffi.ptr(lse), ffi.ptr(t), *none, 1, 4, ffi.stream())
     assert rc != 0
+    # the LayerNorm part needs all of its operands
+    rc = ffi.lib().dkd_attn192_bwd(ffi.ptr(t), ffi.ptr(t), ffi.ptr(t), ffi.ptr(t), ffi.ptr(lse), ffi.ptr(t), ffi.ptr(t), *([None] * 8), 1, 197, ffi.stream())
+    assert rc != 0 and b"qkv_wt" in ffi.lib().dkd_last_error()

@@ -33,8 +33,27 @@ def timeit(fn, iters=30):
     return e0.elapsed_time(e1) / iters * 1e3
 
 
+wq = (torch.randn(192, 576, device=dev) * 192 ** -0.5).to(BF)
+x = torch.randn(B * N, 192, device=dev)
+gam = torch.ones(192, device=dev)
+mean, rstd = x.mean(1).contiguous(), torch.rsqrt(x.var(1, unbiased=False) + 1e-6).contiguous()
+g = torch.zeros(B * N, 192, device=dev)
+dg, db = torch.zeros(192, device=dev), torch.zeros(192, device=dev)
+ws = torch.empty(L.dkd_layernorm_bwd_workspace_bytes(B * N, 192) // 4, device=dev)
+NONE9 = [None] * 9
+
+
 def fused():
-    ffi.check(L.dkd_attn192_bwd(ffi.ptr(dy), ffi.ptr(wpt), ffi.ptr(qkv), ffi.ptr(out), ffi.ptr(lse), ffi.ptr(dqkv), B, N, ffi.stream()), "bwd")
+    ffi.check(L.dkd_attn192_bwd(ffi.ptr(dy), ffi.ptr(wpt), ffi.ptr(qkv), ffi.ptr(out), ffi.ptr(lse), ffi.ptr(dqkv), *NONE9, B, N, ffi.stream()), "bwd")
+
+
+def fused_ln():
+    ffi.check(L.dkd_attn192_bwd(ffi.ptr(dy), ffi.ptr(wpt), ffi.ptr(qkv), ffi.ptr(out), ffi.ptr(lse), ffi.ptr(dqkv), ffi.ptr(wq), ffi.ptr(x), ffi.ptr(gam),
+                                ffi.ptr(mean), ffi.ptr(rstd), ffi.ptr(g), ffi.ptr(dg), ffi.ptr(db), ffi.ptr(ws), B, N, ffi.stream()), "bwd ln")
+
+
+def lnbwd():
+    ops.gemm_nt_lnbwd(dqkv, wq, x, gam, mean, rstd, g, dg, db, ws)
 
 
 def proj_dgrad():
@@ -46,5 +65,6 @@ def attn_bwd():
 
 
 proj_dgrad()
-t_f, t_p, t_a = timeit(fused), timeit(proj_dgrad), timeit(attn_bwd)
-print(f"B {B} N {N}: fused {t_f:.1f} us; proj dgrad {t_p:.1f} + attention backward {t_a:.1f} = {t_p + t_a:.1f} us")
+t_f, t_p, t_a, t_fl, t_l = timeit(fused), timeit(proj_dgrad), timeit(attn_bwd), timeit(fused_ln), timeit(lnbwd)
+print(f"B {B} N {N}: fused {t_f:.1f} us; proj dgrad {t_p:.1f} + attention backward {t_a:.1f} = {t_p + t_a:.1f} us | with the qkv dgrad + LayerNorm "
+      f"backward: fused {t_fl:.1f} us; separate launch {t_l:.1f} us (+ reduction) -> {t_f + t_l:.1f} / {t_p + t_a + t_l:.1f} us")

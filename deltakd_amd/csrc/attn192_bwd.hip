@@ -190,17 +190,18 @@ __device__ __noinline__ void attn192_bwd_phase_c(const Attn192Bwd p, char* smem,
       brow[rg] = p.dqkv + (row0 + (blive[rg] ? r : 0)) * (3 * G_D) + 8 * fg;
     }
     gu32x4 bq[2][6];
-    auto load_b = [&](const int ch, auto kkc) {                      // the two groups' B fragments of K step kk of chunk ch
-      constexpr int kk = decltype(kkc)::value;
-#pragma unroll
-      for (int rg = 0; rg < 2; ++rg) g_issue_gload(brow[rg] + ch * G_D + 32 * kk, bq[rg][kk]);
-    };
-    load_chunk(0, 0);
-    g_static_for<6>([&](auto kkc) { load_b(0, kkc); });
-    load_chunk(1, 1);
-
     auto phase_c = [&](auto ngc) {
       constexpr int NG = decltype(ngc)::value;
+      // the wave's B fragments of K step kk of chunk ch.  ONLY the groups the wave owns: the destination of an asm-issued load nobody
+      // reads is a dead register to the compiler, which hands it to another value while the load is still in flight
+      auto load_b = [&](const int ch, auto kkc) {
+        constexpr int kk = decltype(kkc)::value;
+#pragma unroll
+        for (int rg = 0; rg < NG; ++rg) g_issue_gload(brow[rg] + ch * G_D + 32 * kk, bq[rg][kk]);
+      };
+      load_chunk(0, 0);
+      g_static_for<6>([&](auto kkc) { load_b(0, kkc); });
+      load_chunk(1, 1);
       f32x4 acc[NG][12];
 #pragma unroll
       for (int rg = 0; rg < NG; ++rg)
@@ -403,24 +404,23 @@ __global__ __launch_bounds__(512, 1) void attn192_bwd_kernel(const Attn192Bwd p)
     __builtin_amdgcn_s_waitcnt(0xC07F);                                // lgkmcnt(0)
     __syncthreads();
     load_weights(0);
-    // ---- the wave's dY rows as MFMA B operands, for all three heads (lane (row i16, k group fg): features 32 kk + 8 fg .. + 7)
-    bf16x8 xt[2][6];
+    // ---- the wave's dY rows as MFMA B operands, for all three heads (lane (row i16, k group fg): features 32 kk + 8 fg .. + 7), and the
+    // rows' log-sum-exps: asm loads like everything else here, so that they, head 0's weight image and head 0's q / k / v are all in flight
+    // together (a compiler-placed wait for them would also sit out the q / k / v pieces issued behind them)
+    gu32x4 xraw[2][6];
+    bool xlive[2];
 #pragma unroll
     for (int rg = 0; rg < 2; ++rg) {
       const int r = grp[rg] * 16 + i16;
-      const bool live = rg < ng && r < N;                              // (padded rows: any valid address, zeroed in registers)
-      const bf16_t* src = p.dy + (row0 + (live ? r : 0)) * G_D + 8 * fg;
+      xlive[rg] = rg < ng && r < N;                                    // (padded rows: any valid address, zeroed in registers)
+      const bf16_t* src = p.dy + (row0 + (xlive[rg] ? r : 0)) * G_D + 8 * fg;
 #pragma unroll
-      for (int kk = 0; kk < 6; ++kk) {
-        const uint4 v = *(const uint4*)(src + 32 * kk);
-        xt[rg][kk] = __builtin_bit_cast(bf16x8, live ? v : uint4{0u, 0u, 0u, 0u});
-      }
+      for (int kk = 0; kk < 6; ++kk) g_issue_gload(src + 32 * kk, xraw[rg][kk]);
     }
     float rl[3];                                                        // lse log2(e) of row tid, per head
 #pragma unroll
-    for (int h = 0; h < 3; ++h) rl[h] = tid < N ? p.lse[((size_t)b * G_H + h) * N + tid] * G_LOG2E : 0.f;
-    // (the compiler's waits for the loads above cover everything issued so far; from here on the loop's vector-memory traffic is asm)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    for (int h = 0; h < 3; ++h)
+      asm volatile("global_load_dword %0, %1, off" : "=v"(rl[h]) : "v"(p.lse + ((size_t)b * G_H + h) * N + (tid < N ? tid : 0)) : "memory");
 
 #pragma unroll 1
     for (int h = 0; h < G_H; ++h) {
@@ -434,11 +434,25 @@ __global__ __launch_bounds__(512, 1) void attn192_bwd_kernel(const Attn192Bwd p)
         for (int j = 0; j < 2; ++j) g_issue_gload(p.o + (row0 + rc) * G_D + h * 64 + 32 * j + 8 * fg, ov[rg][j]);
       }
       load_qkv(row0, h);
-      // the weight image of this head (issued before the O loads and the q, k, v pieces) has landed
-      if (h == 0) {                                                     // (first head: the prologue's vmcnt(0) above covered its weight pieces)
-      } else if (nq == 10) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+      // the weight image of this head (and, first head, the dY rows and log-sum-exps) -- everything issued before the 4 O loads and the nq
+      // q / k / v pieces -- has landed
+      if (nq == 10) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
       else if (nq == 9) asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (h == 0) {
+#pragma unroll
+        for (int rg = 0; rg < 2; ++rg)
+#pragma unroll
+          for (int kk = 0; kk < 6; ++kk) {
+            asm volatile("" : "+v"(xraw[rg][kk]));                     // (released by the counted wait above)
+            if (!xlive[rg]) xraw[rg][kk] = gu32x4{0u, 0u, 0u, 0u};
+          }
+#pragma unroll
+        for (int hh = 0; hh < 3; ++hh) {
+          asm volatile("" : "+v"(rl[hh]));
+          rl[hh] = tid < N ? rl[hh] * G_LOG2E : 0.f;
+        }
+      }
       __builtin_amdgcn_s_barrier();
 
       // ================= P: dO of the wave's groups for this head
@@ -460,7 +474,7 @@ __global__ __launch_bounds__(512, 1) void attn192_bwd_kernel(const Attn192Bwd p)
             constexpr int i = decltype(ii)::value, kk = i >> 2, dt = i & 3;
             g_wait<(23 - i < 3 ? 23 - i : 3)>(fr[i & 3]);
 #pragma unroll
-            for (int rg = 0; rg < NG; ++rg) acc[rg][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(g_bf(fr[i & 3]), xt[rg][kk], acc[rg][dt], 0, 0, 0);
+            for (int rg = 0; rg < NG; ++rg) acc[rg][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(g_bf(fr[i & 3]), g_bf(xraw[rg][kk]), acc[rg][dt], 0, 0, 0);
             if constexpr (i + 4 < 24) issue(std::integral_constant<int, i + 4>{});
           });
         }

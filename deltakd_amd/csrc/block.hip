@@ -200,7 +200,7 @@ inline int64_t al256(int64_t bytes) { return (bytes + 255) / 256 * 256; }
 }
 
 extern "C" int64_t dkd_layernorm_bwd_workspace_bytes(int32_t M, int32_t D) {
-  return al256((int64_t)2 * D * ((M + 63) / 64) * 4);
+  return al256((int64_t)2 * D * (((M + 63) / 64) > 320 ? ((M + 63) / 64) : 320) * 4);   // (>= 320 partial rows: the per-sample kernels leave one per workgroup = per CU)
 }
 
 extern "C" int64_t dkd_block_fwd_workspace_bytes(int32_t B, int32_t N, int32_t D, int32_t H, int32_t hidden, int32_t training,

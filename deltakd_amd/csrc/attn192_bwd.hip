@@ -34,13 +34,15 @@ constexpr int G_LSE = G_W + G_W_BYTES, G_NDL = G_LSE + G_ROWS * 4;    // lse log
 constexpr int G_HEADS_END = G_NDL + G_ROWS * 4;                       // 141 056 B: what the head loop uses
 // phase C (qkv dgrad + LayerNorm backward) reuses the images' space: two buffers for a third of qkv.weight^T each ([192 rows, 192 k] bf16)
 constexpr int G_CBUF = 192 * 384;                                     // 73 728 B
+constexpr int G_TSTRIDE = 196;                                        // floats per row of a wave's [16][192] transposition table (phase C)
+static_assert(8 * 16 * G_TSTRIDE * 4 <= 2 * G_CBUF, "the eight waves' tables live in the two weight buffers");
 constexpr int G_RED = 2 * G_CBUF;                                     // f32 [2][192]: this workgroup's partial dgamma | dbeta
 constexpr int G_SMEM = G_RED + 2 * G_D * 4;                           // 148 992 B
 static_assert(G_RED >= G_HEADS_END, "the partial sums must survive the head loops of later samples");
 constexpr float G_LOG2E = 1.4426950408889634f;
 
 // Dev-only ablation bits (build with -DDKD_ATTN192B_ABL=n; results are then wrong, timings are the point): 1 no phase P MFMAs,
-// 2 no phase A, 4 no phase B, 8 no global stores, 16 no q/k/v DMA.
+// 2 no phase A, 4 no phase B, 8 no global stores, 16 no q/k/v DMA, 32 no phase C MFMAs, 64 no LayerNorm epilogue, 128 no dgamma / dbeta sums.
 #ifndef DKD_ATTN192B_ABL
 #define DKD_ATTN192B_ABL 0
 #endif
@@ -199,9 +201,14 @@ __device__ __noinline__ void attn192_bwd_phase_c(const Attn192Bwd p, char* smem,
 #pragma unroll
         for (int rg = 0; rg < NG; ++rg) g_issue_gload(brow[rg] + ch * G_D + 32 * kk, bq[rg][kk]);
       };
+      // the first two chunks do not depend on the head loop's dq / dk / dv stores: they are issued BEFORE those stores are waited for
+      // (vmcnt(18) = everything older than these 18 pieces), so the stores' drain and the chunks' flight overlap; the barrier then makes
+      // every wave's rows visible to the waves that read them back
       load_chunk(0, 0);
-      g_static_for<6>([&](auto kkc) { load_b(0, kkc); });
       load_chunk(1, 1);
+      asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      g_static_for<6>([&](auto kkc) { load_b(0, kkc); });
       f32x4 acc[NG][12];
 #pragma unroll
       for (int rg = 0; rg < NG; ++rg)
@@ -210,10 +217,11 @@ __device__ __noinline__ void attn192_bwd_phase_c(const Attn192Bwd p, char* smem,
 #pragma unroll
       for (int ch = 0; ch < 3; ++ch) {
         const int buf = ch & 1;
-        // chunk ch and its B fragments have landed: everything but the 9 pieces of the chunk issued after them (none after the last)
-        if (ch < 2) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+        // chunk ch and its B fragments have landed: chunk 1 waits for everything but the 9 pieces of chunk 2 issued behind its fragments
+        if (ch == 1) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+
         const uint32_t c0 = lds0 + buf * G_CBUF + i16 * 384 + 16 * (fg ^ ax), c1 = lds0 + buf * G_CBUF + i16 * 384 + 16 * ((4 | fg) ^ ax);
         const uint32_t c0h = c0 + 6 * (16 * 384), c1h = c1 + 6 * (16 * 384);
 #pragma unroll
@@ -233,7 +241,8 @@ __device__ __noinline__ void attn192_bwd_phase_c(const Attn192Bwd p, char* smem,
           constexpr int i = decltype(ii)::value, kk = i / 12, dt = i % 12;
           g_wait<(71 - i < 3 ? 71 - i : 3)>(fr[i & 3]);
 #pragma unroll
-          for (int rg = 0; rg < NG; ++rg) acc[rg][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(g_bf(fr[i & 3]), g_bf(bq[rg][kk]), acc[rg][dt], 0, 0, 0);
+          for (int rg = 0; rg < NG; ++rg)
+            if (!(GABL & 32)) acc[rg][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(g_bf(fr[i & 3]), g_bf(bq[rg][kk]), acc[rg][dt], 0, 0, 0);
           if constexpr (i + 4 < 72) issue(std::integral_constant<int, i + 4>{});
           // K step kk is done: its registers take the next chunk's fragments (an MFMA reads its operands at issue, long before the load returns)
           if constexpr (dt == 11)
@@ -246,9 +255,31 @@ __device__ __noinline__ void attn192_bwd_phase_c(const Attn192Bwd p, char* smem,
         }
       }
       // ---- LayerNorm backward on the wave's rows: dx = rstd (dT gamma - mean(dT gamma) - xhat mean(dT gamma xhat)), g += dx; a lane holds
-      // features 32 j + 8 fg .. + 7 (j = 0..5) of row i16 in tiles 2 j, 2 j + 1; the row's other features sit in the lanes i16 + 16 k
+      // features 32 j + 8 fg .. + 7 (j = 0..5) of row i16 in tiles 2 j, 2 j + 1; the row's other features sit in the lanes i16 + 16 k.
+      // dgamma / dbeta (sums over ROWS, which sit on lanes): the wave transposes through a private LDS table -- it writes its 16 rows x 192
+      // values (row stride 196 floats: conflict-free 16-byte writes), then every lane sums 3 columns over the 16 rows into running
+      // registers; 24 writes + 96 reads per group instead of a 4-step cross-lane reduction for each of 96 values (11 us per sample).
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();                                  // nobody reads the weight buffers any more: they hold the tables now
+      float sgam[3] = {0.f, 0.f, 0.f}, sbet[3] = {0.f, 0.f, 0.f};    // columns lane, lane + 64, lane + 128 of dgamma / dbeta
+      float* tab = (float*)smem + w * (16 * G_TSTRIDE);
+      auto col_sums = [&](float (&acc3)[3]) {                        // (the table was written by this wave: lgkmcnt(0), no barrier)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        float t0 = 0.f, t1 = 0.f, t2 = 0.f;
 #pragma unroll
-      for (int rg = 0; rg < NG; ++rg) {
+        for (int i = 0; i < 16; i += 4) {                            // 12 reads in flight at a time (registers are scarce here)
+#pragma unroll
+          for (int ii = i; ii < i + 4; ++ii) {
+            t0 += tab[ii * G_TSTRIDE + lane_c];
+            t1 += tab[ii * G_TSTRIDE + 64 + lane_c];
+            t2 += tab[ii * G_TSTRIDE + 128 + lane_c];
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(t0), "+v"(t1), "+v"(t2)::"memory");
+        }
+        acc3[0] += t0, acc3[1] += t1, acc3[2] += t2;
+      };
+#pragma unroll
+      for (int rg = 0; rg < NG && !(GABL & 64); ++rg) {
         asm volatile("" ::: "memory");                               // (one group at a time: the loads of the next one stay below this line)
         const int r = grp[rg] * 16 + i16;
         const bool live = r < N;
@@ -256,41 +287,36 @@ __device__ __noinline__ void attn192_bwd_phase_c(const Attn192Bwd p, char* smem,
         const float mu = p.mean[rowp], rs = p.rstd[rowp];
         const float* xr = p.x + rowp * G_D + 8 * fg;
         float* gr = p.g + rowp * G_D + 8 * fg;
-        f32x4 xh[12];
+        f32x4 xh[12];                                                // x, then xhat
+#pragma unroll
+        for (int t = 0; t < 12; ++t) xh[t] = *(const f32x4*)(xr + 32 * (t >> 1) + 4 * (t & 1));
+        float* trow = tab + i16 * G_TSTRIDE + 8 * fg;
+        if (!(GABL & 128)) {                                           // dbeta: the rows' dT (padded rows hold zeros)
+#pragma unroll
+          for (int t = 0; t < 12; ++t) *(f32x4*)(trow + 32 * (t >> 1) + 4 * (t & 1)) = acc[rg][t];
+          col_sums(sbet);
+        }
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int j = 0; j < 6; ++j)
+        for (int t = 0; t < 12; ++t) {
+          const f32x4 gm = *(const f32x4*)(p.gamma + 32 * (t >> 1) + 8 * fg + 4 * (t & 1));
+          f32x4& d = acc[rg][t];
+          f32x4 dg;
 #pragma unroll
-          for (int hf = 0; hf < 2; ++hf) {
-            const f32x4 xv = *(const f32x4*)(xr + 32 * j + 4 * hf);
-            const f32x4 gm = *(const f32x4*)(p.gamma + 32 * j + 8 * fg + 4 * hf);
-            f32x4& d = acc[rg][2 * j + hf];
-            f32x4 pg, pb;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              const float xe = (xv[e] - mu) * rs;
-              xh[2 * j + hf][e] = xe;
-              pb[e] = live ? d[e] : 0.f;
-              pg[e] = pb[e] * xe;
-              d[e] *= gm[e];                                         // gy, kept in the accumulator's registers
-              s1 += d[e];
-              s2 += d[e] * xe;
-            }
-            // partial dgamma / dbeta of these 4 features: the 16 rows of the group, then this workgroup's running sums in LDS
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              pg[e] = g_row_sum16(pg[e]);
-              pb[e] = g_row_sum16(pb[e]);
-            }
-            if (i16 == 0) {
-#pragma unroll
-              for (int e = 0; e < 4; ++e) {
-                atomicAdd(&red[32 * j + 8 * fg + 4 * hf + e], pg[e]);
-                atomicAdd(&red[G_D + 32 * j + 8 * fg + 4 * hf + e], pb[e]);
-              }
-            }
+          for (int e = 0; e < 4; ++e) {
+            const float xe = (xh[t][e] - mu) * rs;
+            xh[t][e] = xe;
+            dg[e] = d[e] * xe;
+            d[e] *= gm[e];                                           // gy, kept in the accumulator's registers
+            s1 += d[e];
+            s2 += d[e] * xe;
           }
-        asm volatile("" ::: "memory");
+          if (!(GABL & 128)) *(f32x4*)(trow + 32 * (t >> 1) + 4 * (t & 1)) = dg;      // dgamma: dT xhat
+        }
+        f32x4 gv[12];                                                // the incoming gradient rows: in flight under the column sums
+#pragma unroll
+        for (int t = 0; t < 12; ++t) gv[t] = *(const f32x4*)(gr + 32 * (t >> 1) + 4 * (t & 1));
+        if (!(GABL & 128)) col_sums(sgam);
         s1 += __shfl_xor(s1, 16, 64);
         s1 += __shfl_xor(s1, 32, 64);
         s2 += __shfl_xor(s2, 16, 64);
@@ -299,17 +325,19 @@ __device__ __noinline__ void attn192_bwd_phase_c(const Attn192Bwd p, char* smem,
         s2 *= 1.f / G_D;
         if (live && (!(GABL & 8) || p.B < 0)) {
 #pragma unroll
-          for (int j = 0; j < 6; ++j)
+          for (int t = 0; t < 12; ++t) {
+            const f32x4& gy = acc[rg][t];
+            f32x4 o;
 #pragma unroll
-            for (int hf = 0; hf < 2; ++hf) {
-              const f32x4 gv = *(const f32x4*)(gr + 32 * j + 4 * hf);
-              const f32x4& gy = acc[rg][2 * j + hf];
-              f32x4 o;
-#pragma unroll
-              for (int e = 0; e < 4; ++e) o[e] = fmaf(rs, gy[e] - s1 - xh[2 * j + hf][e] * s2, gv[e]);
-              *(f32x4*)(gr + 32 * j + 4 * hf) = o;
-            }
+            for (int e = 0; e < 4; ++e) o[e] = fmaf(rs, gy[e] - s1 - xh[t][e] * s2, gv[t][e]);
+            *(f32x4*)(gr + 32 * (t >> 1) + 4 * (t & 1)) = o;
+          }
         }
+      }
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {                                  // eight waves add into the workgroup's running sums
+        atomicAdd(&red[64 * k + lane_c], sgam[k]);
+        atomicAdd(&red[G_D + 64 * k + lane_c], sbet[k]);
       }
     };
     if (ng == 2) phase_c(std::integral_constant<int, 2>{});
@@ -654,7 +682,6 @@ __global__ __launch_bounds__(512, 1) void attn192_bwd_kernel(const Attn192Bwd p)
           }
         }
       }
-      if (h + 1 == G_H && p.wqt) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // phase C reads every wave's dq / dk / dv rows back
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();                                    // everybody is done with this head's images
     }

@@ -346,6 +346,9 @@ __device__ __noinline__ void attn192_bwd_phase_c(const Attn192Bwd p, char* smem,
   }
 }
 
+// LN: the instantiation that goes on to phase C.  A template parameter, not a run-time test of p.wqt: the mere presence of the call site
+// costs the head loop's register allocation 5-6 us per launch (67 against 61 us at batch 256: call ABI, SGPRs parked in VGPR lanes).
+template <bool LN>
 __global__ __launch_bounds__(512, 1) void attn192_bwd_kernel(const Attn192Bwd p) {
   __shared__ __attribute__((aligned(16))) char smem[G_SMEM];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -685,9 +688,9 @@ __global__ __launch_bounds__(512, 1) void attn192_bwd_kernel(const Attn192Bwd p)
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();                                    // everybody is done with this head's images
     }
-    if (p.wqt) attn192_bwd_phase_c(p, smem, row0, lane, w);
+    if constexpr (LN) attn192_bwd_phase_c(p, smem, row0, lane, w);
   }
-  if (p.wqt) {                                                          // this workgroup's partial dgamma | dbeta
+  if constexpr (LN) {                                                   // this workgroup's partial dgamma | dbeta
     __syncthreads();
     for (int i = tid; i < 2 * G_D; i += 512) p.part[(size_t)blockIdx.x * (2 * G_D) + i] = red[i];
   }
@@ -722,7 +725,8 @@ extern "C" int dkd_attn192_bwd(const void* dy, const void* proj_wt, const void* 
   const int grid = B < n_cu ? B : n_cu;
   DKD_CHECK_ARG(!qkv_wt || (int64_t)grid * 2 * G_D * 4 <= dkd_layernorm_bwd_workspace_bytes(B * N, G_D),
                 "attn192_bwd: ws (dkd_layernorm_bwd_workspace_bytes) too small for %d partial rows", grid);
-  hipLaunchKernelGGL(attn192_bwd_kernel, dim3(grid), dim3(512), 0, as_stream(stream), p);
+  if (qkv_wt) hipLaunchKernelGGL(attn192_bwd_kernel<true>, dim3(grid), dim3(512), 0, as_stream(stream), p);
+  else hipLaunchKernelGGL(attn192_bwd_kernel<false>, dim3(grid), dim3(512), 0, as_stream(stream), p);
   DKD_CHECK_LAUNCH("attn192_bwd");
   if (qkv_wt) return dkd_ln_bwd_reduce(ws, grid, d_ln_w, d_ln_b, G_D, stream);
   return DKD_OK;

@@ -155,9 +155,12 @@ extern "C" int dkd_block_bwd(const DkdBlock* bp, const DkdBlockGrads* gp, void* 
   }
   bool branch_done = false;             // the fused kernel has also run the qkv dgrad + norm1's backward
   if (b.fuse_attn && D == 192 && b.H == 3 && b.N >= 8 && b.N <= 208 && getenv("DKD_NO_ATTN_BWD_FUSION") == nullptr) {
-    // proj dgrad + attention backward in one launch (dO is computed head by head into the LDS image the attention backward reads) and,
-    // with the LayerNorm fusion, the qkv dgrad + norm1's backward behind them (DKD_ATTN_BWD_NO_LN=1 keeps that as its own launch: A/B)
-    branch_done = fuse_ln && getenv("DKD_ATTN_BWD_NO_LN") == nullptr;
+    // proj dgrad + attention backward in one launch (dO is computed head by head into the LDS image the attention backward reads).  The
+    // same launch can go on to the qkv dgrad + norm1's backward (DKD_ATTN_BWD_LN=1), but measured at batch 256 (profiles/r04_attn192_bwd_*)
+    // that tail costs 52 us per block inside the per-sample kernel (every CU moves its 453 KB of f32 rows at its own ~25 GB/s, after
+    // the GEMM, with nothing to overlap) against 36.5 us for dkd_gemm_nt_lnbwd on its own, and the step time is the same either way:
+    // the default keeps the separate launch.
+    branch_done = fuse_ln && getenv("DKD_ATTN_BWD_LN") != nullptr;
     if (branch_done)
       TRY(dkd_attn192_bwd(dFa, b.proj_wt, b.qkv, b.o, b.lse, r.dqkv, b.qkv_wt, b.x, b.ln1_w, b.mean1, b.rstd1, r.g, r.d_ln1_w, r.d_ln1_b,
                           ln_ws1, b.B, b.N, st));

@@ -167,10 +167,13 @@ __global__ __launch_bounds__(512, 1) void attn192_fwd_kernel(const Attn192 p) {
 #pragma unroll
     for (int rg = 0; rg < 2; ++rg) {
       const int r = grp[rg] * 16 + li;
-      const int rc = r < N ? r : N - 1;
+      const bool live = rg < ng;                                       // (a group the wave does not own: any valid address, zeroed in registers --
+      const int rc = !live ? 0 : (r < N ? r : N - 1);                  //  `live ? *ptr : zero` compiled to flat loads from a scratch copy of the zeros)
 #pragma unroll
-      for (int kk = 0; kk < 6; ++kk)
-        xt[rg][kk] = rg < ng ? *(const bf16x8*)(p.y1 + (row0 + rc) * Q_D + 32 * kk + 8 * lg) : __builtin_bit_cast(bf16x8, uint4{0u, 0u, 0u, 0u});
+      for (int kk = 0; kk < 6; ++kk) {
+        const uint4 v = *(const uint4*)(p.y1 + (row0 + rc) * Q_D + 32 * kk + 8 * lg);
+        xt[rg][kk] = __builtin_bit_cast(bf16x8, live ? v : uint4{0u, 0u, 0u, 0u});
+      }
     }
     __builtin_amdgcn_s_waitcnt(0x0070);                                // vmcnt(0) lgkmcnt(0): weights of head 0 landed, zero fill / bias written
     if (!(QABL & 16)) __syncthreads();

@@ -364,23 +364,21 @@ __global__ __launch_bounds__(512, 1) void attn192_bwd_kernel(const Attn192Bwd p)
   float* red = (float*)(smem + G_RED);
   for (int i = tid; i < 2 * G_D; i += 512) red[i] = 0.f;
 
-  // ---- LDS-DMA pieces of the weight image: 24 pieces of 1 KiB per head, wave w issues pieces 3 w .. 3 w + 2
-  uint32_t wsrc[3];
-#pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    const int o = (3 * w + k) * 1024 + lane * 16;
-    const int row = o / 384, cb = o % 384;                             // image row (0..63), byte inside the row
-    const int ps = cb >> 4;
-    const int ls = (ps & ~7) | ((ps & 7) ^ ((row >> 1) & 7));          // this physical 16-B slot holds logical slot ls
-    const int t = row >> 4, rho = row & 15;
-    const int feat = 32 * (t >> 1) + 8 * (rho >> 2) + 4 * (t & 1) + (rho & 3);
-    wsrc[k] = (uint32_t)((feat * G_D + ls * 8) * 2);                   // byte offset inside proj.weight^T for head 0
-  }
+  // ---- LDS-DMA pieces of the weight image: 24 pieces of 1 KiB per head, wave w issues pieces 3 w .. 3 w + 2.  (The per-lane source offsets
+  // are recomputed at every use from an opaque copy of the lane index: kept in registers across the head loop they were spilled.)
   auto load_weights = [&](const int h) {
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
+      const int o = (3 * w + k) * 1024 + ln * 16;
+      const int row = o / 384, cb = o % 384;                           // image row (0..63), byte inside the row
+      const int ps = cb >> 4;
+      const int ls = (ps & ~7) | ((ps & 7) ^ ((row >> 1) & 7));        // this physical 16-B slot holds logical slot ls
+      const int t = row >> 4, rho = row & 15;
+      const int feat = 32 * (t >> 1) + 8 * (rho >> 2) + 4 * (t & 1) + (rho & 3);
       const uint32_t dst = lds0 + G_W + (3 * w + k) * 1024;
-      const uint32_t voff = wsrc[k] + (uint32_t)h * (64 * G_D * 2);
+      const uint32_t voff = (uint32_t)(((h * 64 + feat) * G_D + ls * 8) * 2);    // byte offset inside proj.weight^T
 #pragma clang diagnostic push
 #pragma clang diagnostic ignored "-Winline-asm"
       asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(dst), "v"(voff), "s"(p.wpt) : "memory", "m0");
@@ -388,12 +386,14 @@ __global__ __launch_bounds__(512, 1) void attn192_bwd_kernel(const Attn192Bwd p)
     }
   };
   // ---- q, k, v pieces: 3 npc pieces of 8 rows, wave w issues pieces w, w + 8, ...  (lane: row 8 pc + lane / 8, physical chunk lane % 8)
-  const int prow = lane >> 3;
-  const int plc = (lane & 7) ^ (prow & 6);                             // the logical chunk this lane's 16 bytes hold
   const int npieces = 3 * npc;
   const int nq = (npieces - w + 7) >> 3;                               // pieces this wave issues per head (wave-uniform)
   auto load_qkv = [&](const size_t row0, const int h) {
     if (GABL & 16) return;
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
+    const int prow = ln >> 3;
+    const int plc = (ln & 7) ^ (prow & 6);                             // the logical chunk this lane's 16 bytes hold
     for (int idx = w; idx < npieces; idx += 8) {
       const int which = idx / npc, pc = idx - which * npc;
       const int row = pc * 8 + prow;

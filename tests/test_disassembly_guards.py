@@ -1,0 +1,89 @@
+"""Build-time guards on the kernels whose LDS-DMA / asm-issued loads are released by HAND-COUNTED ``s_waitcnt vmcnt(N)``:
+the counts assume that every vector-memory instruction inside the counted regions is one the source issues.  A register spill the
+compiler adds there (``scratch_load`` / ``scratch_store`` are vector-memory operations too) would not make a wait too short -- the
+operations waited for are always OLDER than the spill traffic -- but it would make the compiler put its own ``vmcnt(0)`` in front of the
+reload's first use, i.e. drain the DMA ring, and it is the first symptom of a changed register allocation.  So: disassemble the code
+object inside libdkd.so and require the loops of those kernels to be free of scratch traffic.  CPU-only (llvm-objdump of the built library).
+"""
+import os
+import re
+import subprocess
+import tempfile
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LLVM = "/opt/rocm/lib/llvm/bin"
+LIB = os.path.join(ROOT, "deltakd_amd", "lib", "libdkd.so")
+MAGIC = b"__CLANG_OFFLOAD_BUNDLE__"
+
+
+@pytest.fixture(scope="module")
+def kernels():
+    """{mangled kernel name: [instruction lines]} for every kernel of libdkd.so's gfx950 code objects."""
+    if not (os.path.exists(LIB) and os.path.exists(os.path.join(LLVM, "llvm-objdump"))):
+        pytest.skip("libdkd.so or llvm-objdump not available")
+    out = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        fat = os.path.join(tmp, "fat.bin")
+        subprocess.run([os.path.join(LLVM, "llvm-objcopy"), "--dump-section", f".hip_fatbin={fat}", LIB], check=True)
+        blob = open(fat, "rb").read()
+        starts = [m.start() for m in re.finditer(re.escape(MAGIC), blob)]
+        assert starts, "no offload bundle in libdkd.so"
+        for i, st in enumerate(starts):                     # one bundle per translation unit
+            part = os.path.join(tmp, f"b{i}.bin")
+            open(part, "wb").write(blob[st:starts[i + 1] if i + 1 < len(starts) else len(blob)])
+            co = os.path.join(tmp, f"b{i}.co")
+            r = subprocess.run([os.path.join(LLVM, "clang-offload-bundler"), "--unbundle", "--type=o", f"--input={part}",
+                                "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--output={co}"], capture_output=True)
+            if r.returncode != 0 or not os.path.exists(co) or os.path.getsize(co) == 0:
+                continue
+            dis = subprocess.run([os.path.join(LLVM, "llvm-objdump"), "-d", co], capture_output=True, text=True, check=True).stdout
+            cur = None
+            for line in dis.splitlines():
+                m = re.match(r"^[0-9a-f]+ <([^>]+)>:", line)
+                if m:
+                    cur = m.group(1)
+                    out[cur] = []
+                elif cur is not None and line.strip():
+                    out[cur].append(line.strip())
+    return out
+
+
+def _body(lines):
+    return [ln.split("//")[0].strip() for ln in lines]
+
+
+def _find(kernels, *needles):
+    hits = [k for k in kernels if all(n in k for n in needles)]
+    assert hits, (needles, sorted(kernels)[:5])
+    return hits
+
+
+@pytest.mark.parametrize("needles,what", [
+    (("attn192_bwd_kernel", "ILb0E"), "fused proj dgrad + attention backward (default instantiation)"),
+    (("attn192_fwd_kernel", "ILi12E"), "fused qkv + attention forward (the 197 / 198-token instantiation; the generic-N one may spill)"),
+    (("mlp192_kernel",), "fused MLP forward / backward"),
+])
+def test_counted_vmcnt_kernels_have_no_spill_traffic_in_their_loops(kernels, needles, what):
+    """Between the kernel's first workgroup barrier and its end -- the persistent loop with the LDS-DMA rings -- there must be no scratch
+    (spill) instruction and no flat_ load (flat operations complete out of order: counted vmcnt waits do not cover them)."""
+    for name in _find(kernels, *needles):
+        body = _body(kernels[name])
+        first = next((i for i, ln in enumerate(body) if ln.startswith("s_barrier")), None)
+        assert first is not None, (name, "no barrier?")
+        loop = body[first:]
+        bad = [ln for ln in loop if ln.startswith(("scratch_", "flat_load", "flat_store"))]
+        assert not bad, f"{what} ({name}): {len(bad)} spill / flat instructions inside the counted-wait region, e.g. {bad[:3]}"
+        assert any(ln.startswith("global_load_lds_dwordx4") for ln in loop), (name, "the LDS-DMA pieces should be in this region")
+
+
+def test_attn192_bwd_counted_waits_match_the_issue_pattern(kernels):
+    """dkd_attn192_bwd's head loop: every wait on the q / k / v pieces is one of the counts the source derives from the piece count
+    (vmcnt(nq + 4) and vmcnt(nq) for nq in {9, 10}, or a full drain), and the asm-issued loads it releases are there (4 O-chunk loads per
+    head = global_load_dwordx4 with no compiler wait in between)."""
+    for name in _find(kernels, "attn192_bwd_kernel", "ILb0E"):
+        body = _body(kernels[name])
+        waits = {int(m.group(1)) for ln in body for m in [re.match(r"s_waitcnt vmcnt\((\d+)\)$", ln)] if m}
+        assert {13, 14, 9, 10} <= waits, (name, sorted(waits))
+        assert waits <= {0, 9, 10, 13, 14}, (name, "an unexpected counted wait (compiler-inserted?)", sorted(waits))

@@ -3,7 +3,8 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from deltakd_amd import ops
-B, N = int(sys.argv[1]) if len(sys.argv) > 1 else 300, 197
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+N = int(sys.argv[2]) if len(sys.argv) > 2 else 197
 dev = torch.device("cuda", 0); BF = torch.bfloat16
 g = torch.Generator().manual_seed(1)
 r = lambda *s, scale=1.0: (torch.randn(*s, generator=g) * scale).to(dev)

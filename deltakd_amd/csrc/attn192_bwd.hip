@@ -116,9 +116,30 @@ __device__ __forceinline__ bf16x8 g_pack8(const f32x4& a, const f32x4& b) { retu
 __device__ __forceinline__ void g_issue_gload(const void* ptr, gu32x4& v) {
   asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(ptr) : "memory");
 }
-template <int N>
-__device__ __forceinline__ void g_vmwait(gu32x4& a, gu32x4& b, gu32x4& c, gu32x4& d) {
-  asm volatile("s_waitcnt vmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N) : "memory");
+// Counted wait + release of asm-issued loads, with the count chosen at RUN time inside ONE asm statement.  Round 4 bug, found by poisoning
+// LDS / registers with NaNs: with `if (nq == 10) wait<10>(regs) else if (nq == 9) wait<9>(regs) ...` the compiler satisfied each branch's
+// "+v" ties by COPYING the load destinations into the asm's operand registers in front of the wait -- i.e. while the loads were still in
+// flight -- and the copies held whatever an earlier wave had left in those VGPRs.  No compiler-visible control flow may sit between the issue
+// of such a load and the statement that releases it; the branch over the immediate lives inside the asm.  n: one of 0, 9, 10, 13, 14
+// (anything else waits for everything).
+#define G_VMWAIT_BODY                                                                                                                  \
+  "s_cmp_eq_u32 %[n], 10\n\ts_cbranch_scc1 .Lg_w10_%=\n\ts_cmp_eq_u32 %[n], 9\n\ts_cbranch_scc1 .Lg_w9_%=\n\t"                      \
+  "s_cmp_eq_u32 %[n], 14\n\ts_cbranch_scc1 .Lg_w14_%=\n\ts_cmp_eq_u32 %[n], 13\n\ts_cbranch_scc1 .Lg_w13_%=\n\t"                    \
+  "s_waitcnt vmcnt(0)\n\ts_branch .Lg_wd_%=\n"                                                                                        \
+  ".Lg_w10_%=:\n\ts_waitcnt vmcnt(10)\n\ts_branch .Lg_wd_%=\n"                                                                        \
+  ".Lg_w9_%=:\n\ts_waitcnt vmcnt(9)\n\ts_branch .Lg_wd_%=\n"                                                                          \
+  ".Lg_w14_%=:\n\ts_waitcnt vmcnt(14)\n\ts_branch .Lg_wd_%=\n"                                                                        \
+  ".Lg_w13_%=:\n\ts_waitcnt vmcnt(13)\n"                                                                                             \
+  ".Lg_wd_%=:"
+__device__ __forceinline__ void g_vmwait(const int n, gu32x4& a, gu32x4& b, gu32x4& c, gu32x4& d) {
+  asm volatile(G_VMWAIT_BODY : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : [n] "s"(n) : "memory", "scc");
+}
+__device__ __forceinline__ void g_vmwait_prologue(const int n, gu32x4 (&x)[2][6], float (&l)[3]) {      // 12 dY fragments, 3 log-sum-exps
+  asm volatile(G_VMWAIT_BODY
+               : "+v"(x[0][0]), "+v"(x[0][1]), "+v"(x[0][2]), "+v"(x[0][3]), "+v"(x[0][4]), "+v"(x[0][5]), "+v"(x[1][0]), "+v"(x[1][1]), "+v"(x[1][2]),
+                 "+v"(x[1][3]), "+v"(x[1][4]), "+v"(x[1][5]), "+v"(l[0]), "+v"(l[1]), "+v"(l[2])
+               : [n] "s"(n)
+               : "memory", "scc");
 }
 __device__ __forceinline__ void g_dma16(uint32_t lds_dst, const void* src) {     // one 1-KiB piece: lane l -> LDS bytes dst + 16 l
 #pragma clang diagnostic push
@@ -432,6 +453,9 @@ __global__ __launch_bounds__(512, 1) void attn192_bwd_kernel(const Attn192Bwd p)
       *(uint4*)(smem + G_V + i * 16) = uint4{0u, 0u, 0u, 0u};
     }
     for (int i = nt * 128 + tid; i < G_IMG / 16; i += 512) *(uint4*)(smem + G_DO + i * 16) = uint4{0u, 0u, 0u, 0u};
+    // (and their -delta / 8: phase B reads the statistics of all 14 query tiles; a NaN left in LDS by an earlier kernel would reach dK
+    // through 0 x NaN although those queries' q and dO rows are zero)
+    if (nt * 16 + tid < G_ROWS) ndl_s[nt * 16 + tid] = 0.f;
     __builtin_amdgcn_s_waitcnt(0xC07F);                                // lgkmcnt(0)
     __syncthreads();
     load_weights(0);
@@ -452,10 +476,20 @@ __global__ __launch_bounds__(512, 1) void attn192_bwd_kernel(const Attn192Bwd p)
 #pragma unroll
     for (int h = 0; h < 3; ++h)
       asm volatile("global_load_dword %0, %1, off" : "=v"(rl[h]) : "v"(p.lse + ((size_t)b * G_H + h) * N + (tid < N ? tid : 0)) : "memory");
+    load_qkv(row0, 0);                                                  // (LDS-DMA has no register result: safe to leave in flight across the loop entry)
+    // head 0's weight image, the dY rows and the log-sum-exps have landed: everything but the nq pieces behind them
+    g_vmwait_prologue(nq, xraw, rl);
+#pragma unroll
+    for (int rg = 0; rg < 2; ++rg)
+#pragma unroll
+      for (int kk = 0; kk < 6; ++kk)
+        if (!xlive[rg]) xraw[rg][kk] = gu32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int hh = 0; hh < 3; ++hh) rl[hh] = tid < N ? rl[hh] * G_LOG2E : 0.f;
 
 #pragma unroll 1
     for (int h = 0; h < G_H; ++h) {
-      // O chunks of the wave's rows (8 features per lane and tile pair) for delta, then this head's q, k, v
+      // O chunks of the wave's rows (8 features per lane and tile pair) for delta; issued and released inside this iteration
       gu32x4 ov[2][2];
 #pragma unroll
       for (int rg = 0; rg < 2; ++rg) {
@@ -464,25 +498,12 @@ __global__ __launch_bounds__(512, 1) void attn192_bwd_kernel(const Attn192Bwd p)
 #pragma unroll
         for (int j = 0; j < 2; ++j) g_issue_gload(p.o + (row0 + rc) * G_D + h * 64 + 32 * j + 8 * fg, ov[rg][j]);
       }
-      load_qkv(row0, h);
-      // the weight image of this head (and, first head, the dY rows and log-sum-exps) -- everything issued before the 4 O loads and the nq
-      // q / k / v pieces -- has landed
-      if (nq == 10) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
-      else if (nq == 9) asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      if (h == 0) {
-#pragma unroll
-        for (int rg = 0; rg < 2; ++rg)
-#pragma unroll
-          for (int kk = 0; kk < 6; ++kk) {
-            asm volatile("" : "+v"(xraw[rg][kk]));                     // (released by the counted wait above)
-            if (!xlive[rg]) xraw[rg][kk] = gu32x4{0u, 0u, 0u, 0u};
-          }
-#pragma unroll
-        for (int hh = 0; hh < 3; ++hh) {
-          asm volatile("" : "+v"(rl[hh]));
-          rl[hh] = tid < N ? rl[hh] * G_LOG2E : 0.f;
-        }
+      if (h > 0) {
+        load_qkv(row0, h);                                             // this head's q, k, v (head 0's went out with the prologue)
+        // the weight image of this head -- issued before the 4 O loads and the nq q / k / v pieces -- has landed
+        if (nq == 10) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+        else if (nq == 9) asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
       __builtin_amdgcn_s_barrier();
 
@@ -509,10 +530,8 @@ __global__ __launch_bounds__(512, 1) void attn192_bwd_kernel(const Attn192Bwd p)
             if constexpr (i + 4 < 24) issue(std::integral_constant<int, i + 4>{});
           });
         }
-        // the O chunks: everything but the q, k, v pieces issued after them
-        if (nq == 10) g_vmwait<10>(ov[0][0], ov[0][1], ov[1][0], ov[1][1]);
-        else if (nq == 9) g_vmwait<9>(ov[0][0], ov[0][1], ov[1][0], ov[1][1]);
-        else g_vmwait<0>(ov[0][0], ov[0][1], ov[1][0], ov[1][1]);
+        // the O chunks: everything but the q, k, v pieces issued after them (head 0: its pieces went out BEFORE the O loads)
+        g_vmwait(h == 0 ? 0 : nq, ov[0][0], ov[0][1], ov[1][0], ov[1][1]);
 #pragma unroll
         for (int rg = 0; rg < NG; ++rg) {
           const int r = grp[rg] * 16 + i16;

@@ -162,3 +162,25 @@ def test_attn192_bwd_refuses_what_it_does_not_take(ops):
     # the LayerNorm part needs all of its operands
     rc = ffi.lib().dkd_attn192_bwd(ffi.ptr(t), ffi.ptr(t), ffi.ptr(t), ffi.ptr(t), ffi.ptr(lse), ffi.ptr(t), ffi.ptr(t), *([None] * 8), 1, 197, ffi.stream())
     assert rc != 0 and b"qkv_wt" in ffi.lib().dkd_last_error()
+
+
+def test_attn192_bwd_does_not_read_lds_it_never_wrote(ops):
+    """Regression (round 4): the statistics rows of the padding query tile were never written, so whatever an EARLIER kernel had left in
+    that part of LDS was read -- a NaN there reached dK through 0 x NaN.  Poison the CUs' LDS with NaNs (a kernel that fills 160 KiB per
+    workgroup), then run the backward: finite, and equal to the run before the poisoning."""
+    B, N, H, D = 256, 197, 3, 192
+    y1 = rnd(B * N, D, seed=1).to(BF16)
+    w = rnd(3 * D, D, scale=D ** -0.5, seed=2).to(BF16)
+    bias = rnd(3 * D, scale=0.5, seed=3)
+    wpt = rnd(D, D, scale=D ** -0.5, seed=4).to(BF16)
+    dy = rnd(B * N, D, seed=5).to(BF16)
+    qkv, out, lse = ops.attn192_fwd(y1, w, bias, B, N)
+    ref = ops.attn192_bwd(dy, wpt, qkv, out, lse, B, N)
+    # the wide GEMM kernel owns all 160 KiB of LDS per workgroup: NaN operands leave NaN tiles behind in it on every CU
+    a = torch.full((256 * 256, 768), float("nan"), device=dev(), dtype=BF16)
+    b = torch.full((2304, 768), float("nan"), device=dev(), dtype=BF16)
+    ops.gemm_nt(a, b)
+    got = ops.attn192_bwd(dy, wpt, qkv, out, lse, B, N)
+    torch.cuda.synchronize()
+    assert torch.isfinite(got.float()).all(), "NaN from LDS contents of an earlier kernel"
+    assert torch.equal(got, ref)

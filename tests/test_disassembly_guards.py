@@ -87,3 +87,64 @@ def test_attn192_bwd_counted_waits_match_the_issue_pattern(kernels):
         waits = {int(m.group(1)) for ln in body for m in [re.match(r"s_waitcnt vmcnt\((\d+)\)$", ln)] if m}
         assert {13, 14, 9, 10} <= waits, (name, sorted(waits))
         assert waits <= {0, 9, 10, 13, 14}, (name, "an unexpected counted wait (compiler-inserted?)", sorted(waits))
+
+
+def _regs_of(tok):
+    m = re.fullmatch(r"v\[(\d+):(\d+)\]", tok)
+    if m:
+        return set(range(int(m.group(1)), int(m.group(2)) + 1))
+    m = re.fullmatch(r"v(\d+)", tok)
+    return {int(m.group(1))} if m else set()
+
+
+def _reads_of_in_flight_registers(lines):
+    """Linear scan of a kernel's instructions: the destination of a global / scratch load is "in flight" until an ``s_waitcnt vmcnt(N)``
+    retires it (all but the N youngest vector-memory operations) or the register is written again; any instruction that READS such a
+    register in between is returned.  For compiler-issued loads this can never happen (the compiler waits before the first use); it
+    happens when an asm-issued load's destination is copied / spilled by the compiler before the asm statement that waits for it."""
+    inflight, bad = [], []
+    for ln in lines:
+        parts = ln.replace(",", " ").split()
+        if not parts:
+            continue
+        op, args = parts[0], parts[1:]
+        if op == "s_waitcnt":
+            m = next((re.fullmatch(r"vmcnt\((\d+)\)", a) for a in args if a.startswith("vmcnt")), None)
+            if m:
+                n = int(m.group(1))
+                inflight = inflight[len(inflight) - n:] if n else []
+            continue
+        is_store = op.startswith(("global_store", "scratch_store", "ds_write", "ds_add", "global_atomic", "buffer_store"))
+        pending = set().union(*[d for d in inflight if d]) if inflight else set()
+        for a in (args if is_store else args[1:]):
+            hit = _regs_of(a) & pending
+            if hit:
+                bad.append((ln, sorted(hit)))
+        if not is_store and args:
+            w = _regs_of(args[0])
+            if w:
+                inflight = [None if d is None else (d - w) for d in inflight]
+        if op.startswith(("global_load", "global_store", "global_atomic", "buffer_", "scratch_", "flat_")):
+            if op.startswith(("global_load_lds", "buffer_load_lds")) or is_store or not op.startswith(("global_load", "scratch_load", "buffer_load", "flat_load")):
+                inflight.append(None)
+            else:
+                inflight.append(_regs_of(args[0]))
+            inflight = inflight[-64:]
+    return bad
+
+
+@pytest.mark.parametrize("needles", [("attn192_bwd_kernel", "ILb0E"), ("attn192_bwd_kernel", "ILb1E"), ("attn192_bwd_phase_c",),
+                                     ("attn192_fwd_kernel", "ILi12E"), ("mlp192_kernel",)])
+def test_no_instruction_reads_a_register_whose_load_is_still_in_flight(kernels, needles):
+    """Round 4 bug (found by poisoning LDS / VGPRs with NaNs, tests/test_attn192_gpu.py::test_attn192_bwd_does_not_read_lds_it_never_wrote):
+    dkd_attn192_bwd issues some of its global loads from asm and releases them with a later, counted ``s_waitcnt`` statement tied to the
+    destination registers.  When compiler-visible control flow (``if (nq == 10) wait<10>(..) else if ..``) sat between issue and wait,
+    hipcc satisfied each branch's ties with ``v_mov`` copies of the destinations IN FRONT of the wait -- copies of registers whose data had
+    not arrived.  The waits now branch inside one asm statement; this test keeps it that way for every kernel that uses the idiom."""
+    hits = [k for k in kernels if all(n in k for n in needles)]
+    if not hits and needles == ("attn192_bwd_phase_c",):
+        pytest.skip("phase C was inlined")
+    assert hits, needles
+    for name in hits:
+        bad = _reads_of_in_flight_registers(_body(kernels[name]))
+        assert not bad, f"{name}: {len(bad)} reads of in-flight load destinations, e.g. {bad[:4]}"

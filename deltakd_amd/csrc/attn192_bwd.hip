@@ -111,34 +111,18 @@ __device__ __forceinline__ gu32x4 g_pack8u(const f32x4& a, const f32x4& b) {
   return gu32x4{pack2bf(a[0], a[1]), pack2bf(a[2], a[3]), pack2bf(b[0], b[1]), pack2bf(b[2], b[3])};
 }
 __device__ __forceinline__ bf16x8 g_pack8(const f32x4& a, const f32x4& b) { return __builtin_bit_cast(bf16x8, g_pack8u(a, b)); }
-// vector-memory operations of the head loop, issued from asm (the compiler must not count them: its own vmcnt waits would be wrong in
-// the safe direction only, i.e. drain the DMA) and released by counted waits tied to the registers
-__device__ __forceinline__ void g_issue_gload(const void* ptr, gu32x4& v) {
-  asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(ptr) : "memory");
-}
-// Counted wait + release of asm-issued loads, with the count chosen at RUN time inside ONE asm statement.  Round 4 bug, found by poisoning
-// LDS / registers with NaNs: with `if (nq == 10) wait<10>(regs) else if (nq == 9) wait<9>(regs) ...` the compiler satisfied each branch's
-// "+v" ties by COPYING the load destinations into the asm's operand registers in front of the wait -- i.e. while the loads were still in
-// flight -- and the copies held whatever an earlier wave had left in those VGPRs.  No compiler-visible control flow may sit between the issue
-// of such a load and the statement that releases it; the branch over the immediate lives inside the asm.  n: one of 0, 9, 10, 13, 14
-// (anything else waits for everything).
-#define G_VMWAIT_BODY                                                                                                                  \
-  "s_cmp_eq_u32 %[n], 10\n\ts_cbranch_scc1 .Lg_w10_%=\n\ts_cmp_eq_u32 %[n], 9\n\ts_cbranch_scc1 .Lg_w9_%=\n\t"                      \
-  "s_cmp_eq_u32 %[n], 14\n\ts_cbranch_scc1 .Lg_w14_%=\n\ts_cmp_eq_u32 %[n], 13\n\ts_cbranch_scc1 .Lg_w13_%=\n\t"                    \
-  "s_waitcnt vmcnt(0)\n\ts_branch .Lg_wd_%=\n"                                                                                        \
-  ".Lg_w10_%=:\n\ts_waitcnt vmcnt(10)\n\ts_branch .Lg_wd_%=\n"                                                                        \
-  ".Lg_w9_%=:\n\ts_waitcnt vmcnt(9)\n\ts_branch .Lg_wd_%=\n"                                                                          \
-  ".Lg_w14_%=:\n\ts_waitcnt vmcnt(14)\n\ts_branch .Lg_wd_%=\n"                                                                        \
-  ".Lg_w13_%=:\n\ts_waitcnt vmcnt(13)\n"                                                                                             \
-  ".Lg_wd_%=:"
-__device__ __forceinline__ void g_vmwait(const int n, gu32x4& a, gu32x4& b, gu32x4& c, gu32x4& d) {
-  asm volatile(G_VMWAIT_BODY : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : [n] "s"(n) : "memory", "scc");
-}
-__device__ __forceinline__ void g_vmwait_prologue(const int n, gu32x4 (&x)[2][6], float (&l)[3]) {      // 12 dY fragments, 3 log-sum-exps
-  asm volatile(G_VMWAIT_BODY
-               : "+v"(x[0][0]), "+v"(x[0][1]), "+v"(x[0][2]), "+v"(x[0][3]), "+v"(x[0][4]), "+v"(x[0][5]), "+v"(x[1][0]), "+v"(x[1][1]), "+v"(x[1][2]),
-                 "+v"(x[1][3]), "+v"(x[1][4]), "+v"(x[1][5]), "+v"(l[0]), "+v"(l[1]), "+v"(l[2])
-               : [n] "s"(n)
+// A counted vector-memory wait whose count is chosen at RUN time (n: 12 or 13 LDS-DMA pieces left in flight; anything else waits for
+// everything).  It releases NO registers.  Round 4 lesson, found by poisoning LDS / VGPRs with NaNs: this kernel first issued some global loads
+// from asm ("=v" destinations) and released them with a later wait tied ("+v") to the same variables; under register pressure hipcc
+// satisfied the ties with v_mov COPIES of the destinations placed in front of the wait -- copies of registers whose data had not arrived.
+// Nothing the compiler can name may be in flight here: the head loop's only asynchronous traffic is LDS-DMA (no register result) and
+// stores; the O rows that delta needs travel by LDS-DMA too (into the image that dO then overwrites).
+__device__ __forceinline__ void g_vmwait_pieces(const int n) {
+  asm volatile("s_cmp_eq_u32 %[n], 13\n\ts_cbranch_scc1 .Lg_w13_%=\n\ts_cmp_eq_u32 %[n], 12\n\ts_cbranch_scc1 .Lg_w12_%=\n\t"
+               "s_waitcnt vmcnt(0)\n\ts_branch .Lg_wd_%=\n"
+               ".Lg_w13_%=:\n\ts_waitcnt vmcnt(13)\n\ts_branch .Lg_wd_%=\n"
+               ".Lg_w12_%=:\n\ts_waitcnt vmcnt(12)\n"
+               ".Lg_wd_%=:" ::[n] "s"(n)
                : "memory", "scc");
 }
 __device__ __forceinline__ void g_dma16(uint32_t lds_dst, const void* src) {     // one 1-KiB piece: lane l -> LDS bytes dst + 16 l
@@ -212,16 +196,8 @@ __device__ __noinline__ void attn192_bwd_phase_c(const Attn192Bwd p, char* smem,
       blive[rg] = rg < ng && r < N;
       brow[rg] = p.dqkv + (row0 + (blive[rg] ? r : 0)) * (3 * G_D) + 8 * fg;
     }
-    gu32x4 bq[2][6];
     auto phase_c = [&](auto ngc) {
       constexpr int NG = decltype(ngc)::value;
-      // the wave's B fragments of K step kk of chunk ch.  ONLY the groups the wave owns: the destination of an asm-issued load nobody
-      // reads is a dead register to the compiler, which hands it to another value while the load is still in flight
-      auto load_b = [&](const int ch, auto kkc) {
-        constexpr int kk = decltype(kkc)::value;
-#pragma unroll
-        for (int rg = 0; rg < NG; ++rg) g_issue_gload(brow[rg] + ch * G_D + 32 * kk, bq[rg][kk]);
-      };
       // the first two chunks do not depend on the head loop's dq / dk / dv stores: they are issued BEFORE those stores are waited for
       // (vmcnt(18) = everything older than these 18 pieces), so the stores' drain and the chunks' flight overlap; the barrier then makes
       // every wave's rows visible to the waves that read them back
@@ -229,7 +205,6 @@ __device__ __noinline__ void attn192_bwd_phase_c(const Attn192Bwd p, char* smem,
       load_chunk(1, 1);
       asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
       __builtin_amdgcn_s_barrier();
-      g_static_for<6>([&](auto kkc) { load_b(0, kkc); });
       f32x4 acc[NG][12];
 #pragma unroll
       for (int rg = 0; rg < NG; ++rg)
@@ -238,20 +213,21 @@ __device__ __noinline__ void attn192_bwd_phase_c(const Attn192Bwd p, char* smem,
 #pragma unroll
       for (int ch = 0; ch < 3; ++ch) {
         const int buf = ch & 1;
-        // chunk ch and its B fragments have landed: chunk 1 waits for everything but the 9 pieces of chunk 2 issued behind its fragments
-        if (ch == 1) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-
-        const uint32_t c0 = lds0 + buf * G_CBUF + i16 * 384 + 16 * (fg ^ ax), c1 = lds0 + buf * G_CBUF + i16 * 384 + 16 * ((4 | fg) ^ ax);
-        const uint32_t c0h = c0 + 6 * (16 * 384), c1h = c1 + 6 * (16 * 384);
+        // the wave's B fragments of this chunk: PLAIN loads (no asm-issued register loads in this kernel: see g_vmwait_pieces); the
+        // compiler's wait for them also drains the next chunk's pieces, which have had a chunk's worth of MFMAs to land.  Padded rows:
+        // dT = 0 (nothing for dgamma / dbeta, no dx stored)
+        bf16x8 bq[NG][6];
 #pragma unroll
         for (int rg = 0; rg < NG; ++rg)
 #pragma unroll
           for (int kk = 0; kk < 6; ++kk) {
-            asm volatile("" : "+v"(bq[rg][kk]));                     // (released by the counted wait above)
-            if (!blive[rg]) bq[rg][kk] = gu32x4{0u, 0u, 0u, 0u};     // padded rows: dT = 0 (nothing for dgamma / dbeta, no dx stored)
+            const uint4 v = *(const uint4*)(brow[rg] + ch * G_D + 32 * kk);
+            bq[rg][kk] = __builtin_bit_cast(bf16x8, blive[rg] ? v : uint4{0u, 0u, 0u, 0u});
           }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // chunk ch has landed (this wave's pieces; the barrier: everybody's)
+        __builtin_amdgcn_s_barrier();
+        const uint32_t c0 = lds0 + buf * G_CBUF + i16 * 384 + 16 * (fg ^ ax), c1 = lds0 + buf * G_CBUF + i16 * 384 + 16 * ((4 | fg) ^ ax);
+        const uint32_t c0h = c0 + 6 * (16 * 384), c1h = c1 + 6 * (16 * 384);
         gu32x4 fr[4];
         auto issue = [&](auto ii) {                                  // fragment ii: K step ii / 12, feature tile ii % 12
           constexpr int i = decltype(ii)::value, kk = i / 12, dt = i % 12;
@@ -263,11 +239,8 @@ __device__ __noinline__ void attn192_bwd_phase_c(const Attn192Bwd p, char* smem,
           g_wait<(71 - i < 3 ? 71 - i : 3)>(fr[i & 3]);
 #pragma unroll
           for (int rg = 0; rg < NG; ++rg)
-            if (!(GABL & 32)) acc[rg][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(g_bf(fr[i & 3]), g_bf(bq[rg][kk]), acc[rg][dt], 0, 0, 0);
+            if (!(GABL & 32)) acc[rg][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(g_bf(fr[i & 3]), bq[rg][kk], acc[rg][dt], 0, 0, 0);
           if constexpr (i + 4 < 72) issue(std::integral_constant<int, i + 4>{});
-          // K step kk is done: its registers take the next chunk's fragments (an MFMA reads its operands at issue, long before the load returns)
-          if constexpr (dt == 11)
-            if (ch < 2) load_b(ch + 1, std::integral_constant<int, kk>{});
         });
         if (ch < 2) {
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -406,20 +379,21 @@ __global__ __launch_bounds__(512, 1) void attn192_bwd_kernel(const Attn192Bwd p)
 #pragma clang diagnostic pop
     }
   };
-  // ---- q, k, v pieces: 3 npc pieces of 8 rows, wave w issues pieces w, w + 8, ...  (lane: row 8 pc + lane / 8, physical chunk lane % 8)
-  const int npieces = 3 * npc;
+  // ---- q, k, v and O pieces: 4 npc pieces of 8 rows, wave w issues pieces w, w + 8, ...  (lane: row 8 pc + lane / 8, physical chunk lane % 8).
+  // The head's O rows go into the dO image: phase P reads a row's chunk from exactly the place it then writes dO to.
+  const int npieces = 4 * npc;
   const int nq = (npieces - w + 7) >> 3;                               // pieces this wave issues per head (wave-uniform)
-  auto load_qkv = [&](const size_t row0, const int h) {
+  auto load_qkvo = [&](const size_t row0, const int h) {
     if (GABL & 16) return;
     int ln = lane;
     asm volatile("" : "+v"(ln));
     const int prow = ln >> 3;
     const int plc = (ln & 7) ^ (prow & 6);                             // the logical chunk this lane's 16 bytes hold
     for (int idx = w; idx < npieces; idx += 8) {
-      const int which = idx / npc, pc = idx - which * npc;
+      const int which = idx / npc, pc = idx - which * npc;             // 0 q, 1 k, 2 v, 3 O
       const int row = pc * 8 + prow;
-      const bf16_t* src = row < N ? p.qkv + (row0 + row) * (3 * G_D) + which * G_D + h * 64 + plc * 8 : (const bf16_t*)g_zero_page;
-      g_dma16(lds0 + which * G_IMG + pc * 1024, src);
+      const bf16_t* live = which < 3 ? p.qkv + (row0 + row) * (3 * G_D) + which * G_D + h * 64 + plc * 8 : p.o + (row0 + row) * G_D + h * 64 + plc * 8;
+      g_dma16(lds0 + which * G_IMG + pc * 1024, row < N ? live : (const bf16_t*)g_zero_page);
     }
   };
 
@@ -459,52 +433,32 @@ __global__ __launch_bounds__(512, 1) void attn192_bwd_kernel(const Attn192Bwd p)
     __builtin_amdgcn_s_waitcnt(0xC07F);                                // lgkmcnt(0)
     __syncthreads();
     load_weights(0);
-    // ---- the wave's dY rows as MFMA B operands, for all three heads (lane (row i16, k group fg): features 32 kk + 8 fg .. + 7), and the
-    // rows' log-sum-exps: asm loads like everything else here, so that they, head 0's weight image and head 0's q / k / v are all in flight
-    // together (a compiler-placed wait for them would also sit out the q / k / v pieces issued behind them)
-    gu32x4 xraw[2][6];
-    bool xlive[2];
+    // ---- the wave's dY rows as MFMA B operands, for all three heads (lane (row i16, k group fg): features 32 kk + 8 fg .. + 7), and the rows'
+    // log-sum-exps: plain loads, used (masked / scaled) right here -- the compiler's wait for them also covers head 0's weight pieces
+    // and comes BEFORE any q / k / v / O piece is issued, so it drains nothing
+    bf16x8 xt[2][6];
 #pragma unroll
     for (int rg = 0; rg < 2; ++rg) {
       const int r = grp[rg] * 16 + i16;
-      xlive[rg] = rg < ng && r < N;                                    // (padded rows: any valid address, zeroed in registers)
-      const bf16_t* src = p.dy + (row0 + (xlive[rg] ? r : 0)) * G_D + 8 * fg;
+      const bool live = rg < ng && r < N;                              // (padded rows: any valid address, zeroed in registers)
+      const bf16_t* src = p.dy + (row0 + (live ? r : 0)) * G_D + 8 * fg;
 #pragma unroll
-      for (int kk = 0; kk < 6; ++kk) g_issue_gload(src + 32 * kk, xraw[rg][kk]);
+      for (int kk = 0; kk < 6; ++kk) {
+        const uint4 v = *(const uint4*)(src + 32 * kk);
+        xt[rg][kk] = __builtin_bit_cast(bf16x8, live ? v : uint4{0u, 0u, 0u, 0u});
+      }
     }
     float rl[3];                                                        // lse log2(e) of row tid, per head
 #pragma unroll
-    for (int h = 0; h < 3; ++h)
-      asm volatile("global_load_dword %0, %1, off" : "=v"(rl[h]) : "v"(p.lse + ((size_t)b * G_H + h) * N + (tid < N ? tid : 0)) : "memory");
-    load_qkv(row0, 0);                                                  // (LDS-DMA has no register result: safe to leave in flight across the loop entry)
-    // head 0's weight image, the dY rows and the log-sum-exps have landed: everything but the nq pieces behind them
-    g_vmwait_prologue(nq, xraw, rl);
-#pragma unroll
-    for (int rg = 0; rg < 2; ++rg)
-#pragma unroll
-      for (int kk = 0; kk < 6; ++kk)
-        if (!xlive[rg]) xraw[rg][kk] = gu32x4{0u, 0u, 0u, 0u};
-#pragma unroll
-    for (int hh = 0; hh < 3; ++hh) rl[hh] = tid < N ? rl[hh] * G_LOG2E : 0.f;
+    for (int h = 0; h < 3; ++h) rl[h] = tid < N ? p.lse[((size_t)b * G_H + h) * N + tid] * G_LOG2E : 0.f;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // (belt and braces: nothing is in flight when the pieces go out)
 
 #pragma unroll 1
     for (int h = 0; h < G_H; ++h) {
-      // O chunks of the wave's rows (8 features per lane and tile pair) for delta; issued and released inside this iteration
-      gu32x4 ov[2][2];
-#pragma unroll
-      for (int rg = 0; rg < 2; ++rg) {
-        const int r = grp[rg] * 16 + i16;
-        const int rc = r < N ? r : N - 1;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) g_issue_gload(p.o + (row0 + rc) * G_D + h * 64 + 32 * j + 8 * fg, ov[rg][j]);
-      }
-      if (h > 0) {
-        load_qkv(row0, h);                                             // this head's q, k, v (head 0's went out with the prologue)
-        // the weight image of this head -- issued before the 4 O loads and the nq q / k / v pieces -- has landed
-        if (nq == 10) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
-        else if (nq == 9) asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      }
+      load_qkvo(row0, h);                                              // lands under phase P's GEMM
+      // the weight image of this head -- issued before the pieces just issued (and, from the second head on, behind the previous head's
+      // stores) -- has landed
+      g_vmwait_pieces(nq);
       __builtin_amdgcn_s_barrier();
 
       // ================= P: dO of the wave's groups for this head
@@ -526,12 +480,13 @@ __global__ __launch_bounds__(512, 1) void attn192_bwd_kernel(const Attn192Bwd p)
             constexpr int i = decltype(ii)::value, kk = i >> 2, dt = i & 3;
             g_wait<(23 - i < 3 ? 23 - i : 3)>(fr[i & 3]);
 #pragma unroll
-            for (int rg = 0; rg < NG; ++rg) acc[rg][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(g_bf(fr[i & 3]), g_bf(xraw[rg][kk]), acc[rg][dt], 0, 0, 0);
+            for (int rg = 0; rg < NG; ++rg) acc[rg][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(g_bf(fr[i & 3]), xt[rg][kk], acc[rg][dt], 0, 0, 0);
             if constexpr (i + 4 < 24) issue(std::integral_constant<int, i + 4>{});
           });
         }
-        // the O chunks: everything but the q, k, v pieces issued after them (head 0: its pieces went out BEFORE the O loads)
-        g_vmwait(h == 0 ? 0 : nq, ov[0][0], ov[0][1], ov[1][0], ov[1][1]);
+        // every wave's q / k / v / O pieces have landed (the O rows of this wave's groups were fetched by other waves)
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
 #pragma unroll
         for (int rg = 0; rg < NG; ++rg) {
           const int r = grp[rg] * 16 + i16;
@@ -539,8 +494,9 @@ __global__ __launch_bounds__(512, 1) void attn192_bwd_kernel(const Attn192Bwd p)
 #pragma unroll
           for (int j = 0; j < 2; ++j) {                                // tiles 2 j, 2 j + 1: features 32 j + 8 fg .. + 7 of the head
             const gu32x4 pk = g_pack8u(acc[rg][2 * j], acc[rg][2 * j + 1]);
-            *(gu32x4*)(smem + G_DO + r * 128 + 16 * ((4 * j + fg) ^ (r & 6))) = pk;
-            const bf16x8 a = __builtin_bit_cast(bf16x8, pk), o8 = g_bf(ov[rg][j]);
+            gu32x4* slot = (gu32x4*)(smem + G_DO + r * 128 + 16 * ((4 * j + fg) ^ (r & 6)));
+            const bf16x8 a = __builtin_bit_cast(bf16x8, pk), o8 = g_bf(*slot);     // the O chunk of the same 8 features, then dO in its place
+            *slot = pk;
 #pragma unroll
             for (int e = 0; e < 8; ++e) d = fmaf((float)a[e], (float)o8[e], d);
           }

@@ -21,3 +21,15 @@ if bad.any():
     print("by part (dq, dk, dv):", bad.sum((0, 1, 3, 4)).tolist(), " by head:", bad.sum((0, 1, 2, 4)).tolist())
     print("samples affected:", int(bad.any(1).any(1).any(1).any(1).sum()), " rows affected per sample (first bad sample):",
           torch.nonzero(bad[int(torch.nonzero(bad.flatten(1).any(1))[0])].flatten(1).any(1)).flatten()[:20].tolist())
+d = (got.float() - ref.float()).abs().view(B, N, 3, 3, 64)
+d = torch.nan_to_num(d, nan=1e9)
+print("differs from the clean run: elements", int((d > 0).sum()), "| by part", (d > 0).sum((0, 1, 3, 4)).tolist(), "| by head", (d > 0).sum((0, 1, 2, 4)).tolist(),
+      "| samples", int((d.flatten(1).amax(1) > 0).sum()), "| max diff", d.max().item())
+bs = torch.nonzero(d.flatten(1).amax(1) > 0).flatten()[:6].tolist()
+for b_ in bs:
+    rows = torch.nonzero(d[b_].flatten(1).amax(1) > 0).flatten()
+    print(f"  sample {b_}: {len(rows)} rows differ, first {rows[:10].tolist()} last {rows[-3:].tolist()}; per (part, head) max", d[b_].amax((0, 3)).tolist())
+# a third run, nothing in between: is the kernel deterministic after the poisoning?
+got3 = ops.attn192_bwd(dy, wpt, qkv, out, lse, B, N)
+torch.cuda.synchronize()
+print("third run == second:", bool(torch.equal(got3, got)), " third == clean:", bool(torch.equal(got3, ref)))

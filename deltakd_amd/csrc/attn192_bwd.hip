@@ -419,14 +419,15 @@ __global__ __launch_bounds__(512, 1) void attn192_bwd_kernel(const Attn192Bwd p)
   const int ng = (grp[0] < nt ? 1 : 0) + (grp[1] < nt ? 1 : 0);        // wave-uniform
   for (int b = blockIdx.x; b < p.B; b += gridDim.x) {
     const size_t row0 = (size_t)b * N;
-    // ---- rows neither the DMA (rows < 8 npc of q, k, v) nor phase P (rows < 16 nt of dO) ever writes must read as zeros (phase C of the
-    // previous sample has used the space)
+    // ---- rows the DMA never writes (rows >= 8 npc of q, k, v and of the dO image, whose rows first hold O: phase P multiplies what it
+    // finds there by the padded rows' dO = 0, and 0 x NaN is NaN) must read as zeros -- phase C of the previous sample has used the space,
+    // and LDS starts with whatever the CU's previous kernel left in it
     for (int i = npc * 64 + tid; i < G_IMG / 16; i += 512) {
       *(uint4*)(smem + G_Q + i * 16) = uint4{0u, 0u, 0u, 0u};
       *(uint4*)(smem + G_K + i * 16) = uint4{0u, 0u, 0u, 0u};
       *(uint4*)(smem + G_V + i * 16) = uint4{0u, 0u, 0u, 0u};
     }
-    for (int i = nt * 128 + tid; i < G_IMG / 16; i += 512) *(uint4*)(smem + G_DO + i * 16) = uint4{0u, 0u, 0u, 0u};
+    for (int i = npc * 64 + tid; i < G_IMG / 16; i += 512) *(uint4*)(smem + G_DO + i * 16) = uint4{0u, 0u, 0u, 0u};
     // (and their -delta / 8: phase B reads the statistics of all 14 query tiles; a NaN left in LDS by an earlier kernel would reach dK
     // through 0 x NaN although those queries' q and dO rows are zero)
     if (nt * 16 + tid < G_ROWS) ndl_s[nt * 16 + tid] = 0.f;

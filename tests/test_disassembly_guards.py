@@ -86,6 +86,7 @@ def test_attn192_bwd_counted_waits_match_the_issue_pattern(kernels):
     for name in _find(kernels, "attn192_bwd_kernel", "ILb0E"):
         body = _body(kernels[name])
         waits = {int(m.group(1)) for ln in body for m in [re.match(r"s_waitcnt vmcnt\((\d+)\)", ln)] if m}
+        waits.discard(63)                                   # (how the disassembler prints "no wait on this counter")
         assert {12, 13} <= waits and max(waits) == 13, (name, sorted(waits))
         assert sum(ln.startswith("global_load_lds_dwordx4") for ln in body) >= 4, name
 

@@ -204,7 +204,13 @@ def main():
     student.to(dev)
     teacher.to(dev)
     optimizer = create_optimizer(args, student)
-    model = DataParallel(student, optimizer) if world > 1 else student
+    # DKD_DP_FORCE=1 (with WORLD_SIZE=1 under torch.distributed.run): wrap the student although the world is one rank, so that a one-GPU box
+    # drives the whole N > 1 code path -- broadcast, bucket all-reduces from the block-backward callback, tail sync -- through RCCL
+    force_dp = bool(os.environ.get("DKD_DP_FORCE")) and world == 1 and "RANK" in os.environ
+    if force_dp and not dist.is_initialized():
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group(backend, init_method="env://", **({"device_id": dev} if backend == "nccl" else {}))
+    model = DataParallel(student, optimizer, force=force_dp) if (world > 1 or force_dp) else student
     side = None if a.no_side_stream else torch.cuda.Stream()
     criterion = DistillationLoss(call_base_loss(args), teacher, cfg["distillation_type"], args.alpha, args.tau, teacher_stream=side)
     mixup_fn = Mixup(mixup_alpha=args.mixup, cutmix_alpha=args.cutmix, prob=args.mixup_prob, switch_prob=args.mixup_switch_prob,
@@ -324,7 +330,7 @@ def main():
                                             for k, v in per.items() if k != dom}},
         "roofline_student": roofline_student,
     }
-    if world > 1:
+    if world > 1 or force_dp:
         # what proves the communicator: every rank's device (UUID, index, local rank), gathered THROUGH the process group that reduced
         # the gradients, and the collective library's version
         props = torch.cuda.get_device_properties(dev)
@@ -345,7 +351,7 @@ def main():
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or force_dp:
         dist.destroy_process_group()
 
 

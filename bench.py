@@ -125,6 +125,58 @@ def cpu_baseline(cfg, batch=32, warmup=2, steps=10, budget_s=75.0):
                       f"torch CPU, {threads} threads on {cpus} usable of {os.cpu_count()} logical cpus, {model})"}
 
 
+def measure_traffic_live(config, batch, timeout_s=240):
+    """HBM-side bytes per launch of the NT-GEMM kernels, MEASURED during this run: two short child runs of this script under
+    `rocprofv3 --kernel-trace --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (separate passes, as MI355X_MICROARCH.md prescribes; the program
+    itself after `--`, no env / shell hop), single stream, 2 + 2 steps, before this process touches the GPU.  bytes per launch =
+    (2 FETCH_SIZE + WRITE_SIZE) KiB (gfx950: FETCH_SIZE reports half of a 16-B/lane coalesced stream, WRITE_SIZE is exact).
+    -> ({kernel family: bytes}, note) or (None, why not)."""
+    import collections
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3")
+    if exe is None:
+        return None, "rocprofv3 not on PATH"
+    fams = ("gemm_nt_kernel<64", "gemm_nt_kernel<128", "gemm_nt256_kernel")
+    raw = collections.defaultdict(dict)
+    tmp = tempfile.mkdtemp(prefix="dkd_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp", DKD_BENCH_PMC_CHILD="1")
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, ctr)
+            cmd = [exe, "--kernel-trace", "--pmc", ctr, "-d", out, "-o", "r", "--output-format", "csv", "--", sys.executable,
+                   os.path.abspath(__file__), "--gpus", "1", "--steps", "2", "--warmup", "2", "--config", config, "--batch", str(batch),
+                   "--no-cpu-baseline", "--no-side-stream", "--traffic", "file"]
+            r = subprocess.run(cmd, env=env, cwd="/tmp", capture_output=True, text=True, timeout=timeout_s)
+            if r.returncode != 0:
+                return None, f"rocprofv3 --pmc {ctr} pass failed (rc {r.returncode}): {(r.stderr or r.stdout)[-200:]}"
+            tot, cnt = collections.Counter(), collections.Counter()
+            for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if row["Counter_Name"] != ctr:
+                        continue
+                    fam = next((k for k in fams if k in row["Kernel_Name"]), None)
+                    if fam:
+                        tot[fam] += float(row["Counter_Value"])
+                        cnt[fam] += 1
+            for k in tot:
+                raw[k][ctr] = tot[k] / cnt[k]
+                raw[k]["dispatches"] = cnt[k]
+    except (subprocess.TimeoutExpired, OSError) as e:
+        return None, f"live PMC passes failed: {e}"
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    res = {(k + ">" if k.endswith(("<64", "<128")) else k): (2 * v.get("FETCH_SIZE", 0.0) + v.get("WRITE_SIZE", 0.0)) * 1024
+           for k, v in raw.items() if "FETCH_SIZE" in v and "WRITE_SIZE" in v}
+    if not res:
+        return None, "the PMC passes produced no rows for the NT-GEMM kernels"
+    return res, {"FETCH_SIZE_KiB": {k: v.get("FETCH_SIZE") for k, v in raw.items()}, "WRITE_SIZE_KiB": {k: v.get("WRITE_SIZE") for k, v in raw.items()},
+                 "dispatches": {k: v.get("dispatches") for k, v in raw.items()}}
+
+
 def launch_ranks(n):
     """`python bench.py --gpus N` without a launcher: run `python -m torch.distributed.run --nproc-per-node N bench.py <same args>`
     as a CHILD process (the reference's launch line: exp/lrkd-deit-tiny.sh:14, tools/utils.py:52-63), relay its output (rank 0
@@ -160,10 +212,16 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="per-GPU batch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-side-stream", action="store_true")
+    ap.add_argument("--traffic", choices=("live", "file"), default="live",
+                    help="roofline.traffic: measured now by two rocprofv3 --pmc child passes (N = 1 only), or read from profiles/pmc_traffic.json")
     a = ap.parse_args()
 
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(a.gpus))              # plain `python bench.py --gpus N`: start the N ranks ourselves (child process)
+
+    live_traffic, live_note = None, None
+    if a.traffic == "live" and a.gpus == 1 and "WORLD_SIZE" not in os.environ and not os.environ.get("DKD_BENCH_NO_PMC"):
+        live_traffic, live_note = measure_traffic_live(a.config, a.batch)      # (child processes; this one has not touched the GPU yet)
 
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -305,11 +363,18 @@ def main():
     # summary of the separate `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes of this same command (tools_dev/collect_profiles.sh)
     traffic, traffic_source = None, None
     tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if dom and os.path.exists(tfile):
+    if dom and live_traffic and dom in live_traffic:
+        traffic = live_traffic[dom]
+        traffic_source = {"measured_in_this_run": True,
+                          "how": "two child runs of this command (2 + 2 steps, single stream) under rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc "
+                                 "WRITE_SIZE, separate passes; bytes per launch = (2 FETCH_SIZE + WRITE_SIZE) KiB (gfx950 correction)",
+                          "raw": live_note}
+    elif dom and os.path.exists(tfile):
         tj = json.load(open(tfile))
         traffic = tj.get(a.config, {}).get(dom)
         traffic_source = {"file": "profiles/pmc_traffic.json", "collected_by": tj.get("_source", "tools_dev/collect_profiles.sh"),
-                          "commit": tj.get("_commit"), "measured_in_this_run": False}
+                          "commit": tj.get("_commit"), "measured_in_this_run": False,
+                          "why_not_live": live_note if isinstance(live_note, str) else ("--traffic file" if a.traffic == "file" else "N > 1 or disabled")}
     f_img = 3 * F_FWD[cfg["student"]] + (F_FWD[cfg["teacher"]] if cfg["distillation_type"] != "none" else 0.0)
     ips = world * a.batch * a.steps / dt
     out = {

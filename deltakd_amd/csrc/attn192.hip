@@ -44,6 +44,12 @@ struct Attn192 {
   bf16_t* qkv;            // bf16 [B * N, 576] out
   bf16_t* o;              // bf16 [B * N, 192] out
   float* lse;             // f32 [B, 3, N] out or NULL
+  // PROJ instantiation only: the branch carried through proj and the residual, x1 = x + rowscale[b] (o Wproj^T + bproj)
+  const bf16_t* wproj;    // bf16 [192, 192]: proj.weight (row f = output feature f)
+  const float* bproj;     // f32 [192]
+  const float* x;         // f32 [B * N, 192]: the block's input (the residual)
+  const float* rowscale;  // f32 [B] DropPath scale of the branch, or NULL (= 1)
+  float* x1;              // f32 [B * N, 192] out (may alias x)
   int B, N;
 };
 
@@ -93,7 +99,11 @@ __device__ __forceinline__ bf16x8 q_pack8(const f32x4& a, const f32x4& b) {
 
 // NF: number of leading key tiles known to be full (N >= 16 NF); tile NF gets its padding mask through the MFMA accumulator's initial value
 // (-inf where key >= N, else 0), later tiles are all padding and skipped.  NF = -1: any N, masks applied with selects (attn.hip).
-template <int NF>
+// PROJ: after the three heads the kernel goes on to x1 = x + rowscale (o Wproj^T + bproj) (round 4): proj.weight streams into the weight
+// image's space during the last head's attention, the wave re-reads its own o rows (it has just stored them: L2) as the B operand of
+// a transposed product whose accumulators are 8 consecutive output features of one row per tile pair, and the f32 residual epilogue
+// runs straight from registers.  A template parameter, not a run-time test: see attn192_bwd.hip on what a conditional tail costs.
+template <int NF, bool PROJ>
 __global__ __launch_bounds__(512, 1) void attn192_fwd_kernel(const Attn192 p) {
   __shared__ __attribute__((aligned(16))) char smem[Q_SMEM];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -109,29 +119,47 @@ __global__ __launch_bounds__(512, 1) void attn192_fwd_kernel(const Attn192 p) {
   const float* bl = (const float*)(smem + Q_B_OFF);
   for (int i = tid; i < 3 * Q_D; i += 512) ((float*)(smem + Q_B_OFF))[i] = p.bqkv[i];
 
-  // ---- LDS-DMA pieces of the weight image: 72 pieces of 1 KiB per head, wave w issues pieces 9 w .. 9 w + 8
-  uint32_t srcoff[9];
-#pragma unroll
-  for (int c = 0; c < 9; ++c) {
-    const int o = (9 * w + c) * 1024 + lane * 16;
-    const int row = o / 384, cb = o % 384;                             // image row = feature (which * 64 + d), byte inside the row
-    const int ps = cb >> 4;
-    const int ls = (ps & ~7) | ((ps & 7) ^ ((row >> 1) & 7));          // this physical 16-B slot holds logical slot ls
-    // image row i of a part (q, k or v): tile t = i / 16, row rho in the tile  ->  feature 32 (t / 2) + 8 (rho / 4) + 4 (t % 2) + rho % 4 of the head:
-    // the 4 + 4 accumulator values a lane holds for tiles 2 j and 2 j + 1 are then 8 CONSECUTIVE features (16-byte stores, natural k-slot order)
-    const int i = row & 63, t = i >> 4, rho = i & 15;
-    const int feat = 32 * (t >> 1) + 8 * (rho >> 2) + 4 * (t & 1) + (rho & 3);
-    srcoff[c] = (uint32_t)(((row >> 6) * Q_D + feat) * Q_D + ls * 8);          // element offset inside wqkv for head 0
-  }
+  // ---- LDS-DMA pieces of the weight image: 72 pieces of 1 KiB per head, wave w issues pieces 9 w .. 9 w + 8.  The per-lane source offsets
+  // are recomputed at every use from an opaque copy of the lane index (nine registers held across the head loop were spilled once the
+  // PROJ tail raised the pressure).
   auto load_weights = [&](const int h) {
     if (QABL & 4) return;
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
 #pragma unroll
     for (int c = 0; c < 9; ++c) {
+      const int o = (9 * w + c) * 1024 + ln * 16;
+      const int row = o / 384, cb = o % 384;                             // image row = feature (which * 64 + d), byte inside the row
+      const int ps = cb >> 4;
+      const int ls = (ps & ~7) | ((ps & 7) ^ ((row >> 1) & 7));          // this physical 16-B slot holds logical slot ls
+      // image row i of a part (q, k or v): tile t = i / 16, row rho in the tile  ->  feature 32 (t / 2) + 8 (rho / 4) + 4 (t % 2) + rho % 4 of the head:
+      // the 4 + 4 accumulator values a lane holds for tiles 2 j and 2 j + 1 are then 8 CONSECUTIVE features (16-byte stores, natural k-slot order)
+      const int i = row & 63, t = i >> 4, rho = i & 15;
+      const int feat = 32 * (t >> 1) + 8 * (rho >> 2) + 4 * (t & 1) + (rho & 3);
       const uint32_t dst = lds0 + (9 * w + c) * 1024;
-      const uint32_t voff = (srcoff[c] + (uint32_t)h * (64 * Q_D)) * 2;
+      const uint32_t voff = (uint32_t)((((row >> 6) * Q_D + feat + h * 64) * Q_D + ls * 8) * 2);
 #pragma clang diagnostic push
 #pragma clang diagnostic ignored "-Winline-asm"
       asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(dst), "v"(voff), "s"(p.wqkv) : "memory", "m0");
+#pragma clang diagnostic pop
+    }
+  };
+  auto load_proj_weights = [&]() {          // the same 72 pieces, from proj.weight [192, 192] with all 12 row tiles permuted
+    int ln = lane;
+    asm volatile("" : "+v"(ln));             // (source offsets recomputed here: not worth nine registers across the head loop)
+#pragma unroll
+    for (int c = 0; c < 9; ++c) {
+      const int o = (9 * w + c) * 1024 + ln * 16;
+      const int row = o / 384, cb = o % 384;
+      const int ps = cb >> 4;
+      const int ls = (ps & ~7) | ((ps & 7) ^ ((row >> 1) & 7));
+      const int t = row >> 4, rho = row & 15;
+      const int feat = 32 * (t >> 1) + 8 * (rho >> 2) + 4 * (t & 1) + (rho & 3);
+      const uint32_t dst = lds0 + (9 * w + c) * 1024;
+      const uint32_t voff = (uint32_t)((feat * Q_D + ls * 8) * 2);
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+      asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(dst), "v"(voff), "s"(p.wproj) : "memory", "m0");
 #pragma clang diagnostic pop
     }
   };
@@ -235,7 +263,8 @@ __global__ __launch_bounds__(512, 1) void attn192_fwd_kernel(const Attn192 p) {
       else if (ng == 1) p1(std::integral_constant<int, 1>{});
       __builtin_amdgcn_s_waitcnt(0xC07F);                              // lgkmcnt(0): K / V rows written
       if (!(QABL & 16)) __syncthreads();                               // everybody's K / V rows; nobody reads this head's weights any more
-      load_weights(h + 1 < Q_H ? h + 1 : 0);                           // lands during P2 (after the last head: head 0's again, for the next sample)
+      if (PROJ && h + 1 == Q_H) load_proj_weights();                   // lands during the last head's P2
+      else load_weights(h + 1 < Q_H ? h + 1 : 0);                      // lands during P2 (after the last head: head 0's again, for the next sample)
 
       // ================= P2: attention of the wave's query groups (the tile body of attn_fwd_ring_kernel, csrc/attn.hip)
 #pragma unroll
@@ -330,17 +359,87 @@ __global__ __launch_bounds__(512, 1) void attn192_fwd_kernel(const Attn192 p) {
       else __builtin_amdgcn_s_waitcnt(0x0F70);
       if (!(QABL & 16)) __syncthreads();                               // everybody is done with this head's K / V
     }
+    if constexpr (PROJ) {
+      // ================= proj + residual.  (The weight image holds proj.weight since the last head's end-of-head wait.)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // this wave's o stores are in L2: it reads its own rows back
+      int ln = lane;
+      asm volatile("" : "+v"(ln));                                     // (addresses of this tail are computed HERE, not hoisted above the head loop)
+      const int li = ln & 15, lg = ln >> 4;
+      bf16x8 ob[2][6];
+#pragma unroll
+      for (int rg = 0; rg < 2; ++rg) {
+        const int r = grp[rg] * 16 + li;
+        const bool live = rg < ng && r < N;
+        const bf16_t* src = p.o + (row0 + (live ? r : 0)) * Q_D + 8 * lg;
+#pragma unroll
+        for (int kk = 0; kk < 6; ++kk) {
+          const uint4 v = *(const uint4*)(src + 32 * kk);
+          ob[rg][kk] = __builtin_bit_cast(bf16x8, live ? v : uint4{0u, 0u, 0u, 0u});
+        }
+      }
+      const float sc = p.rowscale ? p.rowscale[b] : 1.f;
+      auto proj = [&](auto ngc) {
+        constexpr int NG = decltype(ngc)::value;
+        f32x4 acc[NG][12];
+#pragma unroll
+        for (int dt = 0; dt < 12; ++dt) {
+          const f32x4 bias = *(const f32x4*)(p.bproj + 32 * (dt >> 1) + 8 * lg + 4 * (dt & 1));       // the lane's 4 features of tile dt
+#pragma unroll
+          for (int rg = 0; rg < NG; ++rg) acc[rg][dt] = bias;
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     // (the compiler's loads are done before the pinned reads start)
+        const uint32_t w0h = wa0 + 6 * (16 * 384), w1h = wa1 + 6 * (16 * 384);
+        qu32x4 fr[4];
+        auto issue = [&](auto ii) {                                    // fragment ii: K step ii / 12, feature tile ii % 12
+          constexpr int i = decltype(ii)::value, kk = i / 12, dt = i % 12;
+          q_issue_row<(dt % 6) * (16 * 384) + (kk >> 1) * 128>(dt < 6 ? ((kk & 1) ? wa1 : wa0) : ((kk & 1) ? w1h : w0h), fr[i & 3]);
+        };
+        q_static_for<4>(issue);
+        q_static_for<72>([&](auto ii) {
+          constexpr int i = decltype(ii)::value, kk = i / 12, dt = i % 12;
+          q_wait<(71 - i < 3 ? 71 - i : 3)>(fr[i & 3]);
+#pragma unroll
+          for (int rg = 0; rg < NG; ++rg) acc[rg][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q_bf(fr[i & 3]), ob[rg][kk], acc[rg][dt], 0, 0, 0);
+          if constexpr (i + 4 < 72) issue(std::integral_constant<int, i + 4>{});
+        });
+#pragma unroll
+        for (int rg = 0; rg < NG; ++rg) {
+          const int r = grp[rg] * 16 + li;
+          if (r >= N) continue;
+          const float* xr = p.x + (row0 + r) * Q_D + 8 * lg;
+          float* yr = p.x1 + (row0 + r) * Q_D + 8 * lg;
+          f32x4 xv[12];
+#pragma unroll
+          for (int dt = 0; dt < 12; ++dt) xv[dt] = *(const f32x4*)(xr + 32 * (dt >> 1) + 4 * (dt & 1));      // (all loads before the first store: x1 may alias x)
+#pragma unroll
+          for (int dt = 0; dt < 12; ++dt) {
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = fmaf(sc, acc[rg][dt][e], xv[dt][e]);
+            *(f32x4*)(yr + 32 * (dt >> 1) + 4 * (dt & 1)) = o;
+          }
+        }
+      };
+      if (ng == 2) proj(std::integral_constant<int, 2>{});
+      else if (ng == 1) proj(std::integral_constant<int, 1>{});
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (!(QABL & 16)) __syncthreads();                               // everybody is done with the proj image
+      load_weights(0);                                                 // head 0's weights for the next sample (if any)
+    }
   }
 }
 
 }  // namespace
 
-extern "C" int dkd_attn192_fwd(const void* y1, const void* wqkv, const float* bqkv, void* qkv, void* o, float* lse, int32_t B, int32_t N,
-                               void* stream) {
+namespace {
+int attn192_launch(const void* y1, const void* wqkv, const float* bqkv, void* qkv, void* o, float* lse, const void* proj_w, const float* proj_b,
+                   const float* x, const float* rowscale, float* x1, int32_t B, int32_t N, void* stream) {
   DKD_CHECK_ARG(y1 && wqkv && bqkv && qkv && o, "attn192_fwd: null operand");
   DKD_CHECK_ARG(B > 0 && N > 0 && N <= 208, "attn192_fwd: need 0 < N <= 208 tokens (N=%d)", N);
   DKD_CHECK_ARG((((uintptr_t)y1 | (uintptr_t)wqkv | (uintptr_t)bqkv | (uintptr_t)qkv | (uintptr_t)o) & 15) == 0, "attn192_fwd: operands must be 16-byte aligned");
   DKD_CHECK_ARG((long)B * N * 576 < (1L << 31), "attn192_fwd: qkv too large for 32-bit offsets");
+  DKD_CHECK_ARG(!proj_w || (proj_b && x && x1 && (((uintptr_t)proj_w | (uintptr_t)proj_b | (uintptr_t)x | (uintptr_t)x1) & 15) == 0),
+                "attn192_fwd_proj: proj_w needs proj_b, x and x1, 16-byte aligned");
   static int n_cu = 0;
   if (!n_cu) {
     int dev = 0;
@@ -353,11 +452,30 @@ extern "C" int dkd_attn192_fwd(const void* y1, const void* wqkv, const float* bq
   }
   Attn192 p;
   p.y1 = (const bf16_t*)y1; p.wqkv = (const bf16_t*)wqkv; p.bqkv = bqkv; p.qkv = (bf16_t*)qkv; p.o = (bf16_t*)o; p.lse = lse;
+  p.wproj = (const bf16_t*)proj_w; p.bproj = proj_b; p.x = x; p.rowscale = rowscale; p.x1 = x1;
   p.B = B; p.N = N;
   const int grid = B < n_cu ? B : n_cu;
   // 197 / 198 tokens: twelve full key tiles, the thirteenth partial (its padding mask rides in the MFMA accumulator), the fourteenth skipped
-  if (N / 16 == 12) hipLaunchKernelGGL(attn192_fwd_kernel<12>, dim3(grid), dim3(512), 0, as_stream(stream), p);
-  else hipLaunchKernelGGL(attn192_fwd_kernel<-1>, dim3(grid), dim3(512), 0, as_stream(stream), p);
+  const bool nf12 = N / 16 == 12;
+  if (proj_w) {
+    if (nf12) hipLaunchKernelGGL((attn192_fwd_kernel<12, true>), dim3(grid), dim3(512), 0, as_stream(stream), p);
+    else hipLaunchKernelGGL((attn192_fwd_kernel<-1, true>), dim3(grid), dim3(512), 0, as_stream(stream), p);
+  } else {
+    if (nf12) hipLaunchKernelGGL((attn192_fwd_kernel<12, false>), dim3(grid), dim3(512), 0, as_stream(stream), p);
+    else hipLaunchKernelGGL((attn192_fwd_kernel<-1, false>), dim3(grid), dim3(512), 0, as_stream(stream), p);
+  }
   DKD_CHECK_LAUNCH("attn192_fwd");
   return DKD_OK;
+}
+}  // namespace
+
+extern "C" int dkd_attn192_fwd(const void* y1, const void* wqkv, const float* bqkv, void* qkv, void* o, float* lse, int32_t B, int32_t N,
+                               void* stream) {
+  return attn192_launch(y1, wqkv, bqkv, qkv, o, lse, nullptr, nullptr, nullptr, nullptr, nullptr, B, N, stream);
+}
+
+extern "C" int dkd_attn192_fwd_proj(const void* y1, const void* wqkv, const float* bqkv, void* qkv, void* o, float* lse, const void* proj_w,
+                                    const float* proj_b, const float* x, const float* rowscale, float* x1, int32_t B, int32_t N, void* stream) {
+  DKD_CHECK_ARG(proj_w, "attn192_fwd_proj: null proj_w");
+  return attn192_launch(y1, wqkv, bqkv, qkv, o, lse, proj_w, proj_b, x, rowscale, x1, B, N, stream);
 }

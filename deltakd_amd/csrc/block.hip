@@ -29,20 +29,26 @@ int block_fwd(const DkdBlock& b, void* st) {
     if (!b.ln1_ready) TRY(dkd_layernorm_fwd(b.x, D, ID, b.ln1_w, b.ln1_b, b.y1, b.mean1, b.rstd1, M, D, b.eps, 0, st));
     g = mk(b.y1, b.qkv_w, b.qkv, M, 3 * D, D);
   }
+  bool proj_done = false;
   if (b.fuse_attn && !(fold & 1)) {       // qkv projection + attention in one launch: q, k, v reach the attention through registers / LDS
-    TRY(dkd_attn192_fwd(b.y1, b.qkv_w, b.qkv_b, b.qkv, b.o, b.lse, b.B, b.N, st));
+    // ... and, unless DKD_NO_ATTN_FWD_PROJ is set (A/B), proj + DropPath + residual behind them in the same launch (round 4)
+    proj_done = !(fold & 2) && getenv("DKD_NO_ATTN_FWD_PROJ") == nullptr;
+    if (proj_done) TRY(dkd_attn192_fwd_proj(b.y1, b.qkv_w, b.qkv_b, b.qkv, b.o, b.lse, b.proj_w, b.proj_b, b.x, b.s1, b.x1, b.B, b.N, st));
+    else TRY(dkd_attn192_fwd(b.y1, b.qkv_w, b.qkv_b, b.qkv, b.o, b.lse, b.B, b.N, st));
   } else {
     g.epi = DKD_EPI_BIAS; g.bias = b.qkv_b;
     TRY(dkd_gemm_nt(&g, st));
     TRY(dkd_attn_fwd(b.qkv, b.o, b.lse, b.B, b.N, b.H, st));
   }
-  g = mk(b.o, b.proj_w, b.x1, M, D, D);
-  g.epi = DKD_EPI_BIAS | DKD_EPI_RESID | DKD_EPI_OUT_F32; g.bias = b.proj_b;
-  g.resid = b.x; g.ldr = D; g.rowscale = b.s1; g.rows_per_sample = b.N;
-  if (fold & 2) {
-    g.xb = b.xb; g.ldxb = D; g.rowstats = b.stats2;
+  if (!proj_done) {
+    g = mk(b.o, b.proj_w, b.x1, M, D, D);
+    g.epi = DKD_EPI_BIAS | DKD_EPI_RESID | DKD_EPI_OUT_F32; g.bias = b.proj_b;
+    g.resid = b.x; g.ldr = D; g.rowscale = b.s1; g.rows_per_sample = b.N;
+    if (fold & 2) {
+      g.xb = b.xb; g.ldxb = D; g.rowstats = b.stats2;
+    }
+    TRY(dkd_gemm_nt(&g, st));
   }
-  TRY(dkd_gemm_nt(&g, st));
   if (b.fuse_mlp) {                       // LN2 + fc1 + GELU + fc2 + tap + DropPath + residual: one kernel, h stays in registers
     const bool save = b.pre != nullptr;
     return dkd_mlp192_fwd(b.x1, b.ln2_w, b.ln2_b, b.eps, b.fc1_w, b.fc1_b, b.fc2_wt, b.fc2_b, b.s2, b.N, b.x2, b.tap, save ? b.y2 : nullptr,

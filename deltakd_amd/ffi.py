@@ -83,6 +83,7 @@ _SIGS = {
     "dkd_gemm_tn_group": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
     "dkd_attn192_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "dkd_attn192_bwd": (C.c_int, [C.c_void_p] * 15 + [C.c_int32, C.c_int32, C.c_void_p]),
+    "dkd_attn192_fwd_proj": (C.c_int, [C.c_void_p] * 11 + [C.c_int32, C.c_int32, C.c_void_p]),
     "dkd_block_wgrad_group": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
     "dkd_ln_bwd_reduce_group": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
     "dkd_conv3x3_wgrad": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),

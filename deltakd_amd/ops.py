@@ -157,6 +157,19 @@ def attn192_fwd(y1, wqkv, bqkv, B, N, need_lse=True):
     return qkv, out, lse
 
 
+def attn192_fwd_proj(y1, wqkv, bqkv, proj_w, proj_b, x, B, N, rowscale=None, need_lse=True):
+    """attn192_fwd carried through proj and the residual: -> (qkv, out, lse, x1 f32 [B*N, 192] = x + rowscale[b] (out proj_w^T + proj_b))."""
+    assert y1.dtype == BF16 and y1.is_contiguous() and wqkv.dtype == BF16 and wqkv.is_contiguous() and bqkv.dtype == F32
+    assert proj_w.dtype == BF16 and proj_w.is_contiguous() and proj_w.shape == (192, 192) and proj_b.dtype == F32 and x.dtype == F32 and x.is_contiguous()
+    qkv = torch.empty(B * N, 576, device=y1.device, dtype=BF16)
+    out = torch.empty(B * N, 192, device=y1.device, dtype=BF16)
+    lse = torch.empty(B, 3, N, device=y1.device, dtype=F32) if need_lse else None
+    x1 = torch.empty_like(x)
+    check(lib().dkd_attn192_fwd_proj(ptr(y1), ptr(wqkv), ptr(bqkv), ptr(qkv), ptr(out), ptr(lse), ptr(proj_w), ptr(proj_b), ptr(x), ptr(rowscale),
+                                     ptr(x1), B, N, stream()), "attn192_fwd_proj")
+    return qkv, out, lse, x1
+
+
 def attn192_bwd(dy, proj_wt, qkv, out, lse, B, N, *, qkv_wt=None, x=None, ln_w=None, mean=None, rstd=None, g=None, d_ln_w=None, d_ln_b=None):
     """dy bf16 [B*N, 192] (gradient w.r.t. proj's output), proj_wt bf16 [192, 192] = proj.weight^T, qkv / out / lse as attn192_fwd returned
     them -> dqkv bf16 [B*N, 576]: proj dgrad + attention backward in one launch (dO never leaves the chip).  With ``qkv_wt`` (bf16 [192, 576] =

@@ -188,6 +188,13 @@ int dkd_mlp192_fwd(const float* x1, const float* ln_w, const float* ln_b, float 
  * head, lse f32 [B, 3, N] (may be NULL).  y1 bf16 [B*N, 192] (norm1 output), wqkv bf16 [576, 192], bqkv f32 [576].  Same results as
  * dkd_gemm_nt(BIAS) + dkd_attn_fwd up to the summation order (DkdBlock.fuse_attn selects it). */
 int dkd_attn192_fwd(const void* y1, const void* wqkv, const float* bqkv, void* qkv, void* o, float* lse, int32_t B, int32_t N, void* stream);
+/* The same launch carried through the rest of the branch ([3P] timm Block: x = x + drop_path(attn(norm1(x))), round 4):
+ *     x1[m, :] = x[m, :] + rowscale[m / N] * (o[m, :] proj_w^T + proj_b)
+ * proj_w bf16 [192, 192] (nn.Linear layout), proj_b f32 [192], x / x1 f32 [B*N, 192] (x1 may alias x), rowscale f32 [B] or NULL (= 1).
+ * qkv, o and lse are written as by dkd_attn192_fwd (the backward reads them).  Same results as dkd_attn192_fwd + dkd_gemm_nt(BIAS | RESID |
+ * OUT_F32, rowscale) up to the summation order. */
+int dkd_attn192_fwd_proj(const void* y1, const void* wqkv, const float* bqkv, void* qkv, void* o, float* lse, const void* proj_w,
+                         const float* proj_b, const float* x, const float* rowscale, float* x1, int32_t B, int32_t N, void* stream);
 /* Backward of the same branch, one launch ([3P] autograd of timm Attention.forward and of the LayerNorm in front of it, reached from
  * the reference's loss_scaler call at tools/engine.py:61-62): dO = dy proj.weight (never written: each head's slice is computed into the
  * LDS image the attention backward reads), then dq, dk, dv per head into dqkv bf16 [B*N, 576] (the qkv weight gradient reads it).

@@ -184,3 +184,34 @@ def test_attn192_bwd_does_not_read_lds_it_never_wrote(ops):
     torch.cuda.synchronize()
     assert torch.isfinite(got.float()).all(), "NaN from LDS contents of an earlier kernel"
     assert torch.equal(got, ref)
+
+
+@pytest.mark.parametrize("B,N,scaled", [(2, 17, True), (5, 197, True), (4, 198, False), (3, 208, True), (300, 197, True), (1, 1, False)])
+def test_attn192_fwd_with_proj_and_residual(ops, B, N, scaled):
+    """dkd_attn192_fwd_proj: the same launch carried through proj + DropPath scale + residual.  qkv / out / lse must be what dkd_attn192_fwd
+    writes (bit for bit: the head loop is the same code); x1 against fp32 torch on the kernel's own (bf16) attention output: 2e-3 of the
+    largest element (fp32 accumulation of bf16 products on both sides, fp32 residual), and against the launch it replaces."""
+    H, D = 3, 192
+    y1 = rnd(B * N, D, seed=1).to(BF16)
+    w = rnd(3 * D, D, scale=D ** -0.5, seed=2).to(BF16)
+    bias = rnd(3 * D, scale=0.5, seed=3)
+    wp = rnd(D, D, scale=D ** -0.5, seed=4).to(BF16)
+    bp = rnd(D, seed=5, scale=0.3)
+    x = rnd(B * N, D, seed=6, scale=2.0)
+    s1 = (torch.rand(B, generator=torch.Generator().manual_seed(7)) > 0.3).float().to(dev()) / 0.7 if scaled else None
+    qkv0, out0, lse0 = ops.attn192_fwd(y1, w, bias, B, N)
+    qkv, out, lse, x1 = ops.attn192_fwd_proj(y1, w, bias, wp, bp, x, B, N, rowscale=s1)
+    torch.cuda.synchronize()
+    assert torch.equal(qkv, qkv0) and torch.equal(out, out0) and torch.equal(lse, lse0)
+    sc = (s1 if s1 is not None else torch.ones(B, device=dev())).repeat_interleave(N)[:, None]
+    ref = x + sc * (out.float() @ wp.float().t() + bp)
+    close(x1, ref, 2e-3, "x1 vs fp32")
+    x1_u = ops.gemm_nt(out, wp, bias=bp, resid=x, rowscale=s1, rows_per_sample=N, out_f32=True)
+    close(x1, x1_u, 1e-3, "x1 vs the proj launch")
+    # in place (x1 aliases x), as the training block runs it when the residual stream is updated in place
+    from deltakd_amd import ffi
+    xa = x.clone()
+    ffi.check(ffi.lib().dkd_attn192_fwd_proj(ffi.ptr(y1), ffi.ptr(w), ffi.ptr(bias), ffi.ptr(qkv), ffi.ptr(out), ffi.ptr(lse), ffi.ptr(wp), ffi.ptr(bp),
+                                             ffi.ptr(xa), ffi.ptr(s1), ffi.ptr(xa), B, N, ffi.stream()), "in place")
+    torch.cuda.synchronize()
+    assert torch.equal(xa, x1)

@@ -33,3 +33,28 @@ def unfused():
 
 
 print(f"B {B} N {N}: fused {timeit(lambda: ops.attn192_fwd(y1, w, bias, B, N)):.1f} us, gemm_nt + attn_fwd {timeit(unfused):.1f} us")
+wp = (torch.randn(192, 192, device=dev) * 192 ** -0.5).to(BF)
+bp = torch.randn(192, device=dev) * 0.1
+x = torch.randn(B * N, 192, device=dev)
+s1 = torch.ones(B, device=dev)
+qkv, out, lse = ops.attn192_fwd(y1, w, bias, B, N)
+x1 = torch.empty_like(x)
+from deltakd_amd import ffi
+L = ffi.lib()
+
+
+def fused_proj():
+    ffi.check(L.dkd_attn192_fwd_proj(ffi.ptr(y1), ffi.ptr(w), ffi.ptr(bias), ffi.ptr(qkv), ffi.ptr(out), ffi.ptr(lse), ffi.ptr(wp), ffi.ptr(bp), ffi.ptr(x),
+                                     ffi.ptr(s1), ffi.ptr(x1), B, N, ffi.stream()), "fwd proj")
+
+
+def fused_only():
+    ffi.check(L.dkd_attn192_fwd(ffi.ptr(y1), ffi.ptr(w), ffi.ptr(bias), ffi.ptr(qkv), ffi.ptr(out), ffi.ptr(lse), B, N, ffi.stream()), "fwd")
+
+
+def proj_launch():
+    ops.gemm_nt(out, wp, out=x1, bias=bp, resid=x, rowscale=s1, rows_per_sample=N, out_f32=True)
+
+
+t_fp, t_f, t_p = timeit(fused_proj), timeit(fused_only), timeit(proj_launch)
+print(f"with proj + residual: one launch {t_fp:.1f} us; qkv + attention {t_f:.1f} + proj launch {t_p:.1f} = {t_f + t_p:.1f} us")

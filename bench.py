@@ -280,7 +280,8 @@ def main():
     pool = [(torch.randn(a.batch, 3, 224, 224, device=dev, generator=g), torch.randint(0, 1000, (a.batch,), device=dev, generator=g))
             for _ in range(n_distinct)]
 
-    class Loader:                        # K synthetic batches already resident in HBM (4 distinct, rotated); mixup gets a fresh copy
+    class Loader:                        # K synthetic batches already resident in HBM (4 distinct, rotated).  Mixup writes its mix to a new
+                                         # tensor (shims.Mixup, inplace=False), so the resident batches are handed out as they are
         def __init__(self, n):
             self.n = n
             self.i = 0
@@ -292,7 +293,7 @@ def main():
             for _ in range(self.n):
                 x, y = pool[Loader.pos % n_distinct]
                 Loader.pos += 1
-                yield x.clone(), y
+                yield (x if mixup_fn is not None and not mixup_fn.inplace else x.clone()), y
     Loader.pos = 0
 
     def run(n):

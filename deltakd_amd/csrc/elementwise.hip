@@ -185,18 +185,21 @@ __global__ void adamw_gated_kernel(float* __restrict__ p, const float* __restric
 }
 
 // Mixup / CutMix on a batch resident in HBM (timm Mixup mode='batch' [3P], reached from tools/engine.py:16-18): sample b is
-// mixed with sample B-1-b.  The pair is processed by ONE thread per element so the update is in place and race-free.
-//   mixup : x_b <- lam x_b + (1-lam) x_{B-1-b}        cutmix: the box [yl,yh) x [xl,xh) of x_b <- that of x_{B-1-b}
-__global__ void mixup_kernel(float* __restrict__ x, int B, int C, int H, int W, float lam, int cutmix, int yl, int yh, int xl, int xh) {
+// mixed with sample B-1-b.  The pair is processed by ONE thread per element so the update may be in place (src == x) and is race-free.
+//   mixup : x_b <- lam s_b + (1-lam) s_{B-1-b}        cutmix: the box [yl,yh) x [xl,xh) of x_b <- that of s_{B-1-b}, the rest s_b
+// src != x (dkd_mixup_to): the same bytes moved as in place, and the caller's batch survives -- a batch that stays resident in HBM across
+// steps needs no copy per step to be mixed again.
+__global__ void mixup_kernel(const float* src, float* x, int B, int C, int H, int W, float lam, int cutmix, int yl, int yh, int xl, int xh) {
   const long per = (long)C * H * W;
   const long total4 = (long)(B / 2) * per / 4;
   for (long t = blockIdx.x * (long)blockDim.x + threadIdx.x; t < total4; t += (long)gridDim.x * blockDim.x) {
     const long e = t * 4;
     const int b = (int)(e / per);
     const long off = e % per;
-    float* pa = x + (long)b * per + off;
-    float* pb = x + (long)(B - 1 - b) * per + off;
-    const f32x4 a = *(const f32x4*)pa, c = *(const f32x4*)pb;
+    const long oa = (long)b * per + off, ob = (long)(B - 1 - b) * per + off;
+    float* pa = x + oa;
+    float* pb = x + ob;
+    const f32x4 a = *(const f32x4*)(src + oa), c = *(const f32x4*)(src + ob);
     f32x4 na, nc;
     if (!cutmix) {
       na = a * lam + c * (1.f - lam);
@@ -341,9 +344,21 @@ extern "C" int dkd_mixup(float* x, int32_t B, int32_t C, int32_t H, int32_t W, f
                          int32_t xh, void* stream) {
   DKD_CHECK_ARG(x && B > 0 && B % 2 == 0, "mixup: batch size should be even (B=%d)", B);
   DKD_CHECK_ARG(W % 4 == 0, "mixup: W=%d must be a multiple of 4", W);
-  hipLaunchKernelGGL(mixup_kernel, dim3(grid_for((long)(B / 2) * C * H * W / 4)), dim3(256), 0, as_stream(stream), x, B, C, H, W, lam, cutmix, yl,
+  hipLaunchKernelGGL(mixup_kernel, dim3(grid_for((long)(B / 2) * C * H * W / 4)), dim3(256), 0, as_stream(stream), x, x, B, C, H, W, lam, cutmix, yl,
                      yh, xl, xh);
   DKD_CHECK_LAUNCH("mixup");
+  return DKD_OK;
+}
+
+extern "C" int dkd_mixup_to(const float* src, float* dst, int32_t B, int32_t C, int32_t H, int32_t W, float lam, int32_t cutmix, int32_t yl,
+                            int32_t yh, int32_t xl, int32_t xh, void* stream) {
+  DKD_CHECK_ARG(src && dst && B > 0 && B % 2 == 0, "mixup_to: batch size should be even (B=%d)", B);
+  DKD_CHECK_ARG(W % 4 == 0, "mixup_to: W=%d must be a multiple of 4", W);
+  const size_t n = (size_t)B * C * H * W;
+  DKD_CHECK_ARG(src == dst || src + n <= dst || dst + n <= src, "mixup_to: src and dst overlap without being the same batch");
+  hipLaunchKernelGGL(mixup_kernel, dim3(grid_for((long)(B / 2) * C * H * W / 4)), dim3(256), 0, as_stream(stream), src, dst, B, C, H, W, lam,
+                     cutmix, yl, yh, xl, xh);
+  DKD_CHECK_LAUNCH("mixup_to");
   return DKD_OK;
 }
 

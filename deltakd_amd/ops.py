@@ -567,6 +567,16 @@ def mixup_(x, lam, box=None):
     return x
 
 
+def mixup(x, lam, box=None):
+    """Mixup / CutMix of a device batch into a NEW tensor (x is left as it is): the same bytes moved as ``mixup_``."""
+    assert x.dtype == F32 and x.is_contiguous() and x.dim() == 4
+    B, Cc, H, W = x.shape
+    yl, yh, xl, xh = box if box is not None else (0, 0, 0, 0)
+    out = torch.empty_like(x)
+    check(lib().dkd_mixup_to(ptr(x), ptr(out), B, Cc, H, W, lam, int(box is not None), int(yl), int(yh), int(xl), int(xh), stream()), "mixup_to")
+    return out
+
+
 def mixup_targets(labels, num_classes, lam, smoothing):
     assert labels.dtype == torch.int64 and labels.is_contiguous()
     out = torch.empty(labels.shape[0], num_classes, device=labels.device, dtype=F32)

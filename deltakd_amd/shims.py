@@ -74,7 +74,7 @@ class Mixup:
     CutMix with probability ``switch_prob`` (random box, lambda corrected to the box area), label-smoothed soft targets."""
 
     def __init__(self, mixup_alpha=1., cutmix_alpha=0., cutmix_minmax=None, prob=1.0, switch_prob=0.5, mode="batch",
-                 correct_lam=True, label_smoothing=0.1, num_classes=1000):
+                 correct_lam=True, label_smoothing=0.1, num_classes=1000, inplace=False):
         if mode != "batch":
             raise ValueError("deltakd_amd.shims.Mixup implements mode='batch'")
         if cutmix_minmax is not None:
@@ -83,6 +83,10 @@ class Mixup:
         self.mix_prob, self.switch_prob = prob, switch_prob
         self.label_smoothing, self.num_classes, self.correct_lam = label_smoothing, num_classes, correct_lam
         self.mixup_enabled = True
+        # device batches only: False (default) returns the mix in a new tensor and leaves the loader's batch alone (same bytes moved; a
+        # batch kept resident in HBM can be mixed again next epoch / step without a copy); True overwrites x as timm does.  The reference's
+        # loop uses the RETURNED tensor only (tools/engine.py:16-18).  Host tensors are always mixed in place, as in timm.
+        self.inplace = inplace
 
     def _params_per_batch(self):
         lam, use_cutmix = 1., False
@@ -113,11 +117,11 @@ class Mixup:
             if self.correct_lam:
                 lam = 1. - (yh - yl) * (xh - xl) / float(H * W)
         if x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and x.shape[-1] % 4 == 0:
-            # batch already resident in HBM: one fused in-place kernel + one soft-target kernel; the
+            # batch already resident in HBM: one fused kernel + one soft-target kernel; the
             # lambda / box draws stay on the host's numpy RNG exactly as in timm
             from . import ops
             if lam != 1.:
-                ops.mixup_(x, float(lam), box)
+                x = ops.mixup_(x, float(lam), box) if self.inplace else ops.mixup(x, float(lam), box)
             tgt = target.to(device=x.device, dtype=torch.int64).contiguous()
             return x, ops.mixup_targets(tgt, self.num_classes, float(lam), self.label_smoothing)
         if lam != 1.:                       # host tensors (the reference mixes before the H2D copy): plain torch

@@ -244,6 +244,10 @@ int dkd_add_rows(const void* x, int32_t x_is_f32, int32_t ldx, float* y, int32_t
  * in place, sample b with sample B-1-b.  cutmix = 0: x_b <- lam x_b + (1-lam) x_{B-1-b}; cutmix = 1: box [yl,yh) x [xl,xh) swapped in. */
 int dkd_mixup(float* x, int32_t B, int32_t C, int32_t H, int32_t W, float lam, int32_t cutmix, int32_t yl, int32_t yh, int32_t xl,
               int32_t xh, void* stream);
+/* The same mix written to dst, src left as it is (src == dst: in place; any other overlap is refused).  Same bytes moved as in place; a
+ * batch that stays resident in HBM across steps can be mixed again without a copy per step. */
+int dkd_mixup_to(const float* src, float* dst, int32_t B, int32_t C, int32_t H, int32_t W, float lam, int32_t cutmix, int32_t yl, int32_t yh,
+                 int32_t xl, int32_t xh, void* stream);
 /* out f32 [B, C] = lam * smooth_onehot(labels[b]) + (1-lam) * smooth_onehot(labels[B-1-b])   (timm mixup_target). */
 int dkd_mixup_targets(const int64_t* labels, float* out, int32_t B, int32_t C, float lam, float smoothing, void* stream);
 /* ema <- decay * ema + (1 - decay) * p over a flat parameter buffer (timm ModelEma [3P], tools/engine.py:68-69). */

@@ -774,17 +774,37 @@ def test_mixup_kernels_match_the_host_path():
     """Device Mixup / CutMix (fused kernels) == the torch host path of the shim, for the same numpy draws."""
     import numpy as np
     from deltakd_amd.shims import Mixup
+    mixed_any = False
     for cutmix_alpha, mixup_alpha in ((0.0, 0.8), (1.0, 0.0), (1.0, 0.8)):
         for seed in (0, 1, 2):
             x = rnd(8, 3, 32, 32, seed=150 + seed)
             y = torch.randint(0, 10, (8,), generator=torch.Generator().manual_seed(seed)).to(dev())
             mix = Mixup(mixup_alpha=mixup_alpha, cutmix_alpha=cutmix_alpha, num_classes=10, label_smoothing=0.1)
             np.random.seed(seed)
-            xd, yd = mix(x.clone(), y)
+            keep = x.clone()
+            xd, yd = mix(x, y)                  # default: the mix in a new tensor, the loader's batch untouched
+            assert torch.equal(x, keep)
+            assert xd.data_ptr() != x.data_ptr() or torch.equal(xd, keep)      # (a Beta(0.8, 0.8) draw can round to lambda = 1: nothing to mix)
             np.random.seed(seed)
             xh, yh = mix(x.cpu().clone(), y.cpu())
             close(xd.cpu(), xh, 1e-6, "mixed images")
             close(yd.cpu(), yh, 1e-6, "soft targets")
+            inpl = Mixup(mixup_alpha=mixup_alpha, cutmix_alpha=cutmix_alpha, num_classes=10, label_smoothing=0.1, inplace=True)
+            np.random.seed(seed)
+            xi, yi = inpl(x, y)                 # timm's behaviour: x itself is overwritten
+            assert xi.data_ptr() == x.data_ptr() and torch.equal(xi, xd) and torch.equal(yi, yd)
+            mixed_any = mixed_any or not torch.equal(xd, keep)
+    assert mixed_any
+
+
+def test_mixup_to_refuses_partly_overlapping_batches():
+    from deltakd_amd import ffi
+    buf = torch.zeros(2 * 4 * 3 * 8 * 8 + 64, device=dev())
+    n = 4 * 3 * 8 * 8
+    src, dst = buf[:n], buf[64:64 + n]
+    rc = ffi.lib().dkd_mixup_to(src.data_ptr(), dst.data_ptr(), 4, 3, 8, 8, 0.3, 0, 0, 0, 0, 0, None)
+    assert rc != 0 and "overlap" in ffi.lib().dkd_last_error().decode()
+    assert ffi.lib().dkd_mixup_to(src.data_ptr(), src.data_ptr(), 4, 3, 8, 8, 0.3, 0, 0, 0, 0, 0, None) == 0      # the same batch: in place
 
 
 def test_ema_on_flat_storage():

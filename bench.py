@@ -122,7 +122,9 @@ def cpu_baseline(cfg, batch=32, warmup=2, steps=10, budget_s=75.0):
         torch.set_num_threads(prev)
     return {"value": batch * done / dt, "unit": "images/s", "cores": threads, "kind": "port",
             "sample": f"{warmup} warm-up + {done} timed steps of batch {batch} (same models, loss and optimizer as the GPU step; fp32 "
-                      f"torch CPU, {threads} threads on {cpus} usable of {os.cpu_count()} logical cpus, {model})"}
+                      f"torch CPU, {threads} threads on {cpus} usable of {os.cpu_count()} logical cpus, {model}"
+                      + ("; its LRKD targets are torch.linalg.svd of each batch's own matrices, model/loss.py:318-326 -- the quantity the GPU "
+                         "leg's default mode converges to on every batch" if kind == "lrkd" else "") + ")"}
 
 
 def measure_traffic_live(config, batch, timeout_s=240):
@@ -135,6 +137,7 @@ def measure_traffic_live(config, batch, timeout_s=240):
     import csv
     import glob
     import shutil
+    import signal
     import subprocess
     import tempfile
     exe = shutil.which("rocprofv3")
@@ -149,10 +152,21 @@ def measure_traffic_live(config, batch, timeout_s=240):
             out = os.path.join(tmp, ctr)
             cmd = [exe, "--kernel-trace", "--pmc", ctr, "-d", out, "-o", "r", "--output-format", "csv", "--", sys.executable,
                    os.path.abspath(__file__), "--gpus", "1", "--steps", "2", "--warmup", "2", "--config", config, "--batch", str(batch),
-                   "--no-cpu-baseline", "--no-side-stream", "--traffic", "file"]
-            r = subprocess.run(cmd, env=env, cwd="/tmp", capture_output=True, text=True, timeout=timeout_s)
-            if r.returncode != 0:
-                return None, f"rocprofv3 --pmc {ctr} pass failed (rc {r.returncode}): {(r.stderr or r.stdout)[-200:]}"
+                   "--no-cpu-baseline", "--no-side-stream", "--traffic", "file", "--no-other-configs"]
+            # own session: on a timeout the WHOLE group goes (rocprofv3 is a launcher; killing only it could leave the python grandchild
+            # holding the GPU under the timed loop -- ADVICE round 4)
+            proc = subprocess.Popen(cmd, env=env, cwd="/tmp", stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
+            try:
+                so, se = proc.communicate(timeout=timeout_s)
+            except subprocess.TimeoutExpired:
+                try:
+                    os.killpg(proc.pid, signal.SIGKILL)
+                except OSError:
+                    pass
+                proc.wait()
+                return None, f"TIMEOUT: the rocprofv3 --pmc {ctr} pass exceeded {timeout_s} s; its process group was killed"
+            if proc.returncode != 0:
+                return None, f"rocprofv3 --pmc {ctr} pass failed (rc {proc.returncode}): {(se or so)[-200:]}"
             tot, cnt = collections.Counter(), collections.Counter()
             for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
                 for row in csv.DictReader(open(f)):
@@ -165,7 +179,7 @@ def measure_traffic_live(config, batch, timeout_s=240):
             for k in tot:
                 raw[k][ctr] = tot[k] / cnt[k]
                 raw[k]["dispatches"] = cnt[k]
-    except (subprocess.TimeoutExpired, OSError) as e:
+    except OSError as e:
         return None, f"live PMC passes failed: {e}"
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
@@ -212,6 +226,7 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="per-GPU batch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-side-stream", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the short runs of the other BASELINE configs (soft, mgd, wasskd)")
     ap.add_argument("--traffic", choices=("live", "file"), default="live",
                     help="roofline.traffic: measured now by two rocprofv3 --pmc child passes (N = 1 only), or read from profiles/pmc_traffic.json")
     a = ap.parse_args()
@@ -220,8 +235,16 @@ def main():
         sys.exit(launch_ranks(a.gpus))              # plain `python bench.py --gpus N`: start the N ranks ourselves (child process)
 
     live_traffic, live_note = None, None
-    if a.traffic == "live" and a.gpus == 1 and "WORLD_SIZE" not in os.environ and not os.environ.get("DKD_BENCH_NO_PMC"):
+    # the live passes are skipped inside a pass (DKD_BENCH_PMC_CHILD) and when this process itself runs under a profiler (rocprofv3 /
+    # rocprofiler-sdk preloads: a nested profiler would inherit their preload and output environment -- ADVICE round 4)
+    profiled = bool(os.environ.get("DKD_BENCH_PMC_CHILD")) or any(k.startswith(("ROCPROF", "ROCPROFILER", "ROCP_")) for k in os.environ) \
+        or "rocprof" in os.environ.get("LD_PRELOAD", "")
+    if a.traffic == "live" and a.gpus == 1 and "WORLD_SIZE" not in os.environ and not os.environ.get("DKD_BENCH_NO_PMC") and not profiled:
         live_traffic, live_note = measure_traffic_live(a.config, a.batch)      # (child processes; this one has not touched the GPU yet)
+        if live_traffic is None and isinstance(live_note, str) and live_note.startswith("TIMEOUT"):
+            sys.exit("bench.py: " + live_note + " -- not timing with a possible stray GPU holder; rerun, or pass --traffic file")
+    elif profiled and a.traffic == "live":
+        live_note = "this process runs under a profiler: live PMC passes skipped"
 
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -253,51 +276,55 @@ def main():
     from deltakd_amd.optim import create_optimizer
     from deltakd_amd.shims import Mixup, NativeScaler
 
-    cfg = CONFIGS[a.config]
-    args = make_args(cfg, a.batch)
-    args.rank = rank
-    torch.manual_seed(42)
-    np.random.seed(42 + rank)
-    teacher, student = load_teacher_student_model(cfg["teacher"], cfg["student"], args.drop_path_rate, args)
-    student.to(dev)
-    teacher.to(dev)
-    optimizer = create_optimizer(args, student)
-    # DKD_DP_FORCE=1 (with WORLD_SIZE=1 under torch.distributed.run): wrap the student although the world is one rank, so that a one-GPU box
-    # drives the whole N > 1 code path -- broadcast, bucket all-reduces from the block-backward callback, tail sync -- through RCCL
-    force_dp = bool(os.environ.get("DKD_DP_FORCE")) and world == 1 and "RANK" in os.environ
-    if force_dp and not dist.is_initialized():
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend, init_method="env://", **({"device_id": dev} if backend == "nccl" else {}))
-    model = DataParallel(student, optimizer, force=force_dp) if (world > 1 or force_dp) else student
-    side = None if a.no_side_stream else torch.cuda.Stream()
-    criterion = DistillationLoss(call_base_loss(args), teacher, cfg["distillation_type"], args.alpha, args.tau, teacher_stream=side)
-    mixup_fn = Mixup(mixup_alpha=args.mixup, cutmix_alpha=args.cutmix, prob=args.mixup_prob, switch_prob=args.mixup_switch_prob,
-                     label_smoothing=args.smoothing, num_classes=1000)
-    scaler = NativeScaler()
+    n_distinct = 4                       # distinct synthetic batches, rotated: the LRKD subspace solver sees changing teacher taps
 
-    g = torch.Generator(device=dev).manual_seed(42 + rank)
-    n_distinct = 4                       # distinct synthetic batches, rotated: the LRKD subspace tracking sees changing teacher taps
-    pool = [(torch.randn(a.batch, 3, 224, 224, device=dev, generator=g), torch.randint(0, 1000, (a.batch,), device=dev, generator=g))
-            for _ in range(n_distinct)]
+    def build(config):
+        """Models, optimizer, criterion and the K-batch loop of one BASELINE config -> (run(n), criterion, model, cfg)."""
+        cfg = CONFIGS[config]
+        args = make_args(cfg, a.batch)
+        args.rank = rank
+        torch.manual_seed(42)
+        np.random.seed(42 + rank)
+        teacher, student = load_teacher_student_model(cfg["teacher"], cfg["student"], args.drop_path_rate, args)
+        student.to(dev)
+        teacher.to(dev)
+        optimizer = create_optimizer(args, student)
+        # DKD_DP_FORCE=1 (with WORLD_SIZE=1 under torch.distributed.run): wrap the student although the world is one rank, so that a one-GPU box
+        # drives the whole N > 1 code path -- broadcast, bucket all-reduces from the block-backward callback, tail sync -- through RCCL
+        force = bool(os.environ.get("DKD_DP_FORCE")) and world == 1 and "RANK" in os.environ
+        if force and not dist.is_initialized():
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            dist.init_process_group(backend, init_method="env://", **({"device_id": dev} if backend == "nccl" else {}))
+        model = DataParallel(student, optimizer, force=force) if (world > 1 or force) else student
+        side = None if a.no_side_stream else torch.cuda.Stream()
+        criterion = DistillationLoss(call_base_loss(args), teacher, cfg["distillation_type"], args.alpha, args.tau, teacher_stream=side)
+        mixup_fn = Mixup(mixup_alpha=args.mixup, cutmix_alpha=args.cutmix, prob=args.mixup_prob, switch_prob=args.mixup_switch_prob,
+                         label_smoothing=args.smoothing, num_classes=1000)
+        scaler = NativeScaler()
+        g = torch.Generator(device=dev).manual_seed(42 + rank)
+        pool = [(torch.randn(a.batch, 3, 224, 224, device=dev, generator=g), torch.randint(0, 1000, (a.batch,), device=dev, generator=g))
+                for _ in range(n_distinct)]
+        pos = [0]
 
-    class Loader:                        # K synthetic batches already resident in HBM (4 distinct, rotated).  Mixup writes its mix to a new
+        class Loader:                    # K synthetic batches already resident in HBM (4 distinct, rotated).  Mixup writes its mix to a new
                                          # tensor (shims.Mixup, inplace=False), so the resident batches are handed out as they are
-        def __init__(self, n):
-            self.n = n
-            self.i = 0
+            def __init__(self, n):
+                self.n = n
 
-        def __len__(self):
-            return self.n
+            def __len__(self):
+                return self.n
 
-        def __iter__(self):
-            for _ in range(self.n):
-                x, y = pool[Loader.pos % n_distinct]
-                Loader.pos += 1
-                yield (x if mixup_fn is not None and not mixup_fn.inplace else x.clone()), y
-    Loader.pos = 0
+            def __iter__(self):
+                for _ in range(self.n):
+                    x, y = pool[pos[0] % n_distinct]
+                    pos[0] += 1
+                    yield (x if mixup_fn is not None and not mixup_fn.inplace else x.clone()), y
 
-    def run(n):
-        return train_one_epoch(model, teacher, Loader(n), criterion, optimizer, scaler, None, mixup_fn, None, dev, 0, args)
+        def run(n):
+            return train_one_epoch(model, teacher, Loader(n), criterion, optimizer, scaler, None, mixup_fn, None, dev, 0, args)
+        return run, criterion, model, cfg, force
+
+    run, criterion, model, cfg, force_dp = build(a.config)
 
     def fence():
         if world > 1:
@@ -388,7 +415,9 @@ def main():
                                f"bs {a.batch}/GPU, 3x224x224 synthetic ({n_distinct} distinct batches rotated), 1000 classes, mixup/cutmix on, drop_path 0.1, AdamW",
                    "global_batch": world * a.batch, "parallelism": f"dp{world}",
                    "model_flops_per_image": f_img, "step_mfma_frac_of_2.5PF": ips * f_img / (world * 2.5e15),
-                   "train_loss": stats.get("train_loss")},
+                   "train_loss": stats.get("train_loss"),
+                   # which LRKD target computation was timed (deltakd_amd.losses.LowRankTargets; the default converges every batch)
+                   "lrkd_mode": criterion.lowrank.mode if cfg["distillation_type"] == "lrkd" else None},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": 2500.0, "unit": "TFLOP/s", "frac": achieved / 2500.0,
                      "traffic": traffic, "traffic_source": traffic_source, "kernel": dom, "launches": launches, "avg_launch_us": ms / max(launches, 1) * 1e3,
                      "flop_per_launch_avg": flops / max(launches, 1),
@@ -413,6 +442,33 @@ def main():
                        "overlapped_grad_buckets": getattr(model, "n_buckets", None),
                        "allreduce_calls_per_step": getattr(model, "collectives", 0) / max(1, a.steps + a.warmup),
                        "allreduce_bytes_per_step": getattr(model, "bytes_reduced", 0) / max(1, a.steps + a.warmup)}
+    # BASELINE.json configs 2, 3, 5 beside the headline: soft, mgd, wasskd-L1 for 2 + 5 steps each on the same
+    # box, same loop, no probe / PMC / CPU leg -- short runs: the headline's models are released first
+    if world == 1 and not force_dp and not a.no_other_configs and a.config == "lrkd":
+        others = {}
+        del run, criterion, model
+        import gc
+        gc.collect()
+        torch.cuda.empty_cache()
+        for name in ("soft", "mgd", "wasskd"):
+            try:
+                r2, c2, m2, cf2, _ = build(name)
+                r2(2)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                r2(5)
+                torch.cuda.synchronize()
+                d2 = time.perf_counter() - t1
+                fi = 3 * F_FWD[cf2["student"]] + F_FWD[cf2["teacher"]]
+                others[name] = {"value": a.batch * 5 / d2, "unit": "images/s", "ms_per_step": d2 / 5 * 1e3, "steps": 5, "warmup": 2,
+                                "step_mfma_frac": a.batch * 5 / d2 * fi / 2.5e15, "models": f"{cf2['student']} <- {cf2['teacher']}",
+                                "model_flops_per_image_excl_loss_net": fi}
+                del r2, c2, m2
+                gc.collect()
+                torch.cuda.empty_cache()
+            except Exception as e:                  # a failing side config must not lose the headline line
+                others[name] = {"error": f"{type(e).__name__}: {e}"[:300]}
+        out["other_configs"] = others
     if rank == 0:
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg)

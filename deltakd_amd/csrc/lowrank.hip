@@ -230,7 +230,7 @@ __global__ __launch_bounds__(1024) void jacobi_eigh_kernel(const float* __restri
 
 // ------------------------------------------------------------------------------------------------ the 96 x 96 stage
 // C = A B or A^T B on 96 x 96 matrices in LDS: 1024 threads, each a 3 x 3 block of rows {ty, ty+32, ty+64} x cols {tx, tx+32, tx+64}.
-template <bool TRANS_A, bool TRANS_B = false>
+template <bool TRANS_A, bool TRANS_B = false, int LLD = LB + 1>
 __device__ void mm96(const float* A, const float* B, float* C) {
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   float acc[3][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
@@ -255,6 +255,7 @@ __device__ void mm96(const float* A, const float* B, float* C) {
 // In-place Cholesky of the SPD matrix A (lower triangle used; unit-scaled input): on return the lower triangle holds L with
 // A = L L^T.  Right-looking, one barrier per column; a pivot that fp32 cancellation drove below `floor_` is clamped (the column then
 // carries no weight instead of NaN).
+template <int LLD = LB + 1>
 __device__ void cholesky_lds(float* A, float floor_) {
   const int tid = threadIdx.x, nt = blockDim.x;
   for (int k = 0; k < LB; ++k) {
@@ -278,6 +279,7 @@ __device__ void cholesky_lds(float* A, float floor_) {
 }
 
 // X = L^-1 (lower triangular) by forward substitution, one thread per column (the row of L being read is a broadcast).
+template <int LLD = LB + 1>
 __device__ void tri_inverse_lds(const float* Lm, float* X) {
   const int tid = threadIdx.x, nt = blockDim.x;
   for (int w = tid; w < LB * LB; w += nt) X[(w / LB) * LLD + (w % LB)] = 0.f;
@@ -398,6 +400,610 @@ __global__ __launch_bounds__(1024) void lowrank_small_kernel(const float* __rest
   }
 }
 
+
+// ================================================================================================ round 5: the converged chain
+// dkd_lowrank_chain: n power steps per batch from the previous batch's basis, ending in a converged Rayleigh-Ritz step -- the setting
+// that reproduces the reference's per-batch exact svd (model/loss.py:318-326) -- as a chain of SHORT launches (a long-lived 3-CU kernel
+// holds every 256-workgroup kernel of the other streams back by its own duration: round 4's 8-step setting cost 12.8 ms of chain):
+//     lr_mult_kernel      Y' = (G Y) C   16 rows of Y' per workgroup (K = Dt streamed through LDS, the 16 x Dt row panel of the
+//                         symmetric G resident), the previous stage's 96 x 96 transform C applied to the finished tile -- an
+//                         orthonormalised V = Y C is never materialised between steps: G (Y C) = (G Y) C -- and the tile's
+//                         contribution to S = Y'^T Y' (and P = Y^T Y' in the last stage) added atomically
+//     lr_orth_kernel      S -> C = D^-1 L^-T, Cholesky of the column-scaled S (order-preserving Gram-Schmidt)    one workgroup per layer
+//     lr_ritz_kernel      last stage: H = C_prev^T P = V^T G V, Jacobi H = W E W^T, S' = W^T S W = D L L^T D, C = W D^-1 L^-T
+//     sgemm_kernel<0>     V = Y' C, with the bf16 hi / lo split of V_k^T
+// Schedule for n multiplies: 1, 2, 2, ..., 1 multiplies per stage -- two multiplies between orthonormalisations square the
+// contamination by the dominant directions ((lambda_1 / lambda_j)^2 ~ 2e3 at the 64th vector of a deit_base tap: 1e5 in the
+// condition number of the scaled S, which fp32 Cholesky takes), three do not fit (tools_dev/lowrank_proto_algo.py); the first stage
+// stays single because there the basis is the previous batch's.
+constexpr int LDJ = LB + 2;        // EVEN row stride: the float2 accesses of an index pair's two adjacent columns stay 8-byte aligned
+constexpr int LR_ROWS = 16;
+constexpr int LR_APPLY_C = 1, LR_GRAM_S = 2, LR_GRAM_P = 4;
+
+// dev-only (-DDKD_LR_STAMPS, tools_dev/lowrank_stamps.py): s_memrealtime (100 MHz) at phase boundaries of workgroup 0 of each kernel
+#ifdef DKD_LR_STAMPS
+__device__ unsigned long long lr_stamp_buf[3][64];
+#define LR_STAMP(kern_, n_)                                                                         \
+  do {                                                                                              \
+    if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0) lr_stamp_buf[kern_][n_] = wall_clock64(); \
+  } while (0)
+#else
+#define LR_STAMP(kern_, n_) do { } while (0)
+#endif
+
+__global__ __launch_bounds__(256) void lr_mult_kernel(const float* __restrict__ G, const float* __restrict__ Bsrc, const float* __restrict__ Cg,
+                                                      float* __restrict__ Yout, float* __restrict__ Sg, float* __restrict__ Pg, int Dt,
+                                                      int flags) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int lda = Dt + 4;
+  const int as_floats = LR_ROWS * lda;
+  float* As = sm;                   // [16][Dt + 4] row panel of G
+  float* Bs = sm + as_floats;       // [2][32][96] K chunks of the right operand; later the tiles Zt | Yt | Pt [16][96]
+  float* Cs = Bs + 2 * 32 * LB;     // [96][96] the previous stage's transform
+  const int tid = threadIdx.x, tx = tid & 31, ty = tid >> 5;
+  const int m0 = blockIdx.x * LR_ROWS, layer = blockIdx.y;
+  G += (size_t)layer * Dt * Dt;
+  Bsrc += (size_t)layer * Dt * LB;
+  Yout += (size_t)layer * Dt * LB;
+  LR_STAMP(0, 0);
+  if (flags & LR_APPLY_C) {          // (whole: 9 float4 per thread, consumed in the epilogue)
+    const float* Cl = Cg + (size_t)layer * LB * LB;
+    f32x4 cv[9];
+#pragma unroll
+    for (int e = 0; e < 9; ++e) cv[e] = *(const f32x4*)&Cl[4 * (tid + 256 * e)];
+#pragma unroll
+    for (int e = 0; e < 9; ++e) *(f32x4*)&Cs[4 * (tid + 256 * e)] = cv[e];
+  }
+  // ---- the row panel: G is symmetric with only its 128 x 128 tiles on and above the diagonal valid (dkd_gram): columns left of this
+  // row block's diagonal tile are read as the transposed element.  4 Dt float4 items per workgroup, requested EIGHT per thread at a
+  // time before the first is stored (a load-store loop with a run-time trip count exposed one memory round trip per item: ~20 us).
+  const int kdir = (m0 >> 7) << 7;
+  {
+    const int nk4 = (Dt - kdir) >> 2, nmir = kdir * 4, total = 4 * Dt;
+    for (int base = 0; base < total; base += 256 * 8) {
+      f32x4 v[8];
+      int dst[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int idx = base + tid + 256 * e;
+        dst[e] = -1;
+        if (idx < nmir) {
+          const int k = idx >> 2, r4 = idx & 3;
+          v[e] = *(const f32x4*)&G[(size_t)k * Dt + m0 + 4 * r4];
+          dst[e] = (4 * r4) * lda + k;                     // transposed: four rows, one column
+        } else if (idx < total) {
+          const int id2 = idx - nmir, r = id2 / nk4, k4 = id2 - r * nk4;
+          v[e] = *(const f32x4*)&G[(size_t)(m0 + r) * Dt + kdir + 4 * k4];
+          dst[e] = (r * lda + kdir + 4 * k4) | (1 << 30);   // flag: a row segment
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        if (dst[e] < 0) continue;
+        if (dst[e] & (1 << 30)) {
+          *(f32x4*)&As[dst[e] & ~(1 << 30)] = v[e];
+        } else {
+          As[dst[e]] = v[e][0];
+          As[dst[e] + lda] = v[e][1];
+          As[dst[e] + 2 * lda] = v[e][2];
+          As[dst[e] + 3 * lda] = v[e][3];
+        }
+      }
+    }
+  }
+  // The right operand travels through a ring of FOUR register sets: chunk c + 4 is requested when chunk c is multiplied and written to
+  // LDS three iterations later (one chunk of FMAs is ~0.5 us, a load from L2 / HBM 1-2 us: with one chunk of lookahead the loop ran at
+  // the load latency, 56 us per launch).
+  const int f0 = tid, f1 = tid + 256, f2 = tid + 512;
+  const int fo0 = (f0 / 24) * LB + 4 * (f0 % 24), fo1 = (f1 / 24) * LB + 4 * (f1 % 24), fo2 = (f2 / 24) * LB + 4 * (f2 % 24);
+  f32x4 nb[4][3];
+  const int nchunk = Dt >> 5;
+#define LR_FETCH(slot_, c_)                                                   \
+  if ((c_) < nchunk) {                                                        \
+    const float* src_ = Bsrc + (size_t)(c_) * 32 * LB;                        \
+    nb[slot_][0] = *(const f32x4*)&src_[fo0];                                 \
+    nb[slot_][1] = *(const f32x4*)&src_[fo1];                                 \
+    nb[slot_][2] = *(const f32x4*)&src_[fo2];                                 \
+  }
+#define LR_STASH(slot_, c_)                                                   \
+  if ((c_) < nchunk) {                                                        \
+    float* dst_ = Bs + ((c_) & 1) * 32 * LB;                                  \
+    *(f32x4*)&dst_[fo0] = nb[slot_][0];                                       \
+    *(f32x4*)&dst_[fo1] = nb[slot_][1];                                       \
+    *(f32x4*)&dst_[fo2] = nb[slot_][2];                                       \
+  }
+  LR_FETCH(0, 0)
+  LR_FETCH(1, 1)
+  LR_FETCH(2, 2)
+  LR_FETCH(3, 3)
+  LR_STASH(0, 0)
+  __syncthreads();
+  LR_STAMP(0, 1);
+  float acc[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+  const float* a0p = As + (2 * ty) * lda;
+  const float* a1p = a0p + lda;
+#define LR_STEP(slot_, c_)                                                    \
+  if ((c_) < nchunk) {                                                        \
+    LR_FETCH(slot_, (c_) + 4)                                                 \
+    const float* bp = Bs + ((c_) & 1) * 32 * LB + tx;                         \
+    const int k0 = (c_) << 5;                                                 \
+    _Pragma("unroll") for (int kk = 0; kk < 32; kk += 4) {                    \
+      const f32x4 a0 = *(const f32x4*)&a0p[k0 + kk], a1 = *(const f32x4*)&a1p[k0 + kk]; \
+      _Pragma("unroll") for (int u = 0; u < 4; ++u) {                         \
+        _Pragma("unroll") for (int j = 0; j < 3; ++j) {                       \
+          const float b = bp[(kk + u) * LB + 32 * j];                         \
+          acc[0][j] = fmaf(a0[u], b, acc[0][j]);                              \
+          acc[1][j] = fmaf(a1[u], b, acc[1][j]);                              \
+        }                                                                     \
+      }                                                                       \
+    }                                                                         \
+    LR_STASH(((slot_) + 1) & 3, (c_) + 1)                                     \
+    __syncthreads();                                                          \
+  }
+  for (int c = 0; c < nchunk; c += 4) {
+    LR_STEP(0, c)
+    LR_STEP(1, c + 1)
+    LR_STEP(2, c + 2)
+    LR_STEP(3, c + 3)
+  }
+#undef LR_STEP
+  LR_STAMP(0, 2);
+#undef LR_FETCH
+#undef LR_STASH
+  // ---- epilogue: the tile through the transform, out, and into the 96 x 96 Gram matrices
+  float* Zt = Bs;                  // [16][96]
+  float* Yt = Bs + LR_ROWS * LB;
+  float* Pt = Yt + LR_ROWS * LB;
+  float y[2][3];
+  if (flags & LR_APPLY_C) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) Zt[(2 * ty + i) * LB + tx + 32 * j] = acc[i][j];
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) y[i][j] = 0.f;
+    const float* z0 = Zt + (2 * ty) * LB;
+    const float* z1 = z0 + LB;
+#pragma unroll 2
+    for (int k = 0; k < LB; k += 4) {
+      const f32x4 a0 = *(const f32x4*)&z0[k], a1 = *(const f32x4*)&z1[k];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          const float b = Cs[(k + u) * LB + tx + 32 * j];
+          y[0][j] = fmaf(a0[u], b, y[0][j]);
+          y[1][j] = fmaf(a1[u], b, y[1][j]);
+        }
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) y[i][j] = acc[i][j];
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      Yout[(size_t)(m0 + 2 * ty + i) * LB + tx + 32 * j] = y[i][j];
+      Yt[(2 * ty + i) * LB + tx + 32 * j] = y[i][j];
+    }
+  if (!(flags & (LR_GRAM_S | LR_GRAM_P))) return;
+  LR_STAMP(0, 3);
+  if (flags & LR_GRAM_P)
+    for (int idx = tid; idx < LR_ROWS * LB / 4; idx += 256) *(float4*)&Pt[4 * idx] = *(const float4*)&Bsrc[(size_t)m0 * LB + 4 * idx];
+  __syncthreads();
+  // thread: rows i = ty + 8 m (m < 12) x columns j = tx + 32 n (n < 3) of the 96 x 96 partial products over this block's 16 rows
+  float s[12][3], p[12][3];
+#pragma unroll
+  for (int m = 0; m < 12; ++m)
+#pragma unroll
+    for (int n = 0; n < 3; ++n) s[m][n] = p[m][n] = 0.f;
+  const bool want_p = flags & LR_GRAM_P;
+#pragma unroll 2
+  for (int r = 0; r < LR_ROWS; ++r) {
+    float yj[3];
+#pragma unroll
+    for (int n = 0; n < 3; ++n) yj[n] = Yt[r * LB + tx + 32 * n];
+#pragma unroll
+    for (int m = 0; m < 12; ++m) {
+      const float yi = Yt[r * LB + ty + 8 * m];
+#pragma unroll
+      for (int n = 0; n < 3; ++n) s[m][n] = fmaf(yi, yj[n], s[m][n]);
+    }
+    if (want_p) {
+#pragma unroll
+      for (int m = 0; m < 12; ++m) {
+        const float pi = Pt[r * LB + ty + 8 * m];
+#pragma unroll
+        for (int n = 0; n < 3; ++n) p[m][n] = fmaf(pi, yj[n], p[m][n]);
+      }
+    }
+  }
+  LR_STAMP(0, 4);
+  float* Sl = Sg + (size_t)layer * LB * LB;
+  float* Pl = Pg + (size_t)layer * LB * LB;
+#pragma unroll
+  for (int m = 0; m < 12; ++m)
+#pragma unroll
+    for (int n = 0; n < 3; ++n) {
+      const int o = (ty + 8 * m) * LB + tx + 32 * n;
+      if (flags & LR_GRAM_S) atomicAdd(&Sl[o], s[m][n]);
+      if (want_p) atomicAdd(&Pl[o], p[m][n]);
+    }
+  LR_STAMP(0, 5);
+}
+
+// ---- Cholesky and triangular inverse for the chain's stages (1024 threads, row stride LDJ).  The first forms above spend their time in
+// integer divisions (every work item decodes (i, j) from a flat index by a run-time extent: ~100 us for 96 columns) and in a
+// one-thread-per-column substitution whose every step is an LDS round trip (~55 us).
+// Cholesky: right-looking, one barrier per column; the trailing update is a fixed 32 x 32 thread grid over 3 x 3 elements each.
+__device__ void cholesky96(float* A, float floor_) {
+  const int tid = threadIdx.x, tx = tid & 31, ty = tid >> 5;
+  for (int k = 0; k < LB; ++k) {
+    __syncthreads();
+    const float inv = 1.f / fmaxf(A[k * LDJ + k], floor_);
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const int i = ty + 32 * a;
+      if (i <= k) continue;
+      const float lik = A[i * LDJ + k] * inv;
+#pragma unroll
+      for (int b = 0; b < 3; ++b) {
+        const int j = tx + 32 * b;
+        if (j > k && j <= i) A[i * LDJ + j] -= lik * A[j * LDJ + k];
+      }
+    }
+  }
+  __syncthreads();
+  float sc[3][3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {              // L[i][k] = A[i][k] / sqrt(piv_k); the diagonal is read by everybody first
+      const int i = ty + 32 * a, kk = tx + 32 * b;
+      sc[a][b] = i > kk ? A[i * LDJ + kk] * rsqrtf(fmaxf(A[kk * LDJ + kk], floor_)) : (i == kk ? sqrtf(fmaxf(A[kk * LDJ + kk], floor_)) : 0.f);
+    }
+  __syncthreads();
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int b = 0; b < 3; ++b) A[(ty + 32 * a) * LDJ + tx + 32 * b] = sc[a][b];      // (upper triangle zeroed: the inverse below reads full rows)
+  __syncthreads();
+}
+
+// One level of the recursive inverse of a lower-triangular matrix: for every pair of adjacent M x M diagonal blocks whose inverses
+// X11, X22 are in place,  X21 = -X22 (L21 X11).  T: scratch of the same shape.
+template <int M>
+__device__ void tri_inverse_level(const float* Lm, float* X, float* T) {
+  const int tid = threadIdx.x, nt = blockDim.x;
+  constexpr int NPAIR = LB / (2 * M);
+  for (int o = tid; o < NPAIR * M * M; o += nt) {           // T = L21 X11  (X11 lower triangular: k >= j)
+    const int p = o / (M * M), rem = o - p * M * M, i = rem / M, j = rem - i * M;
+    const int r0 = (2 * p + 1) * M, c0 = 2 * p * M;
+    float acc = 0.f;
+    for (int k = j; k < M; ++k) acc = fmaf(Lm[(r0 + i) * LDJ + c0 + k], X[(c0 + k) * LDJ + c0 + j], acc);
+    T[(r0 + i) * LDJ + c0 + j] = acc;
+  }
+  __syncthreads();
+  for (int o = tid; o < NPAIR * M * M; o += nt) {           // X21 = -X22 T   (X22 lower triangular: k <= i)
+    const int p = o / (M * M), rem = o - p * M * M, i = rem / M, j = rem - i * M;
+    const int r0 = (2 * p + 1) * M, c0 = 2 * p * M;
+    float acc = 0.f;
+    for (int k = 0; k <= i; ++k) acc = fmaf(X[(r0 + i) * LDJ + r0 + k], T[(r0 + k) * LDJ + c0 + j], acc);
+    X[(r0 + i) * LDJ + c0 + j] = -acc;
+  }
+  __syncthreads();
+}
+
+// X = L^-1: the eight 12 x 12 diagonal blocks by substitution (one thread per column, 78 steps), then three levels of pairing
+// (12 -> 24 -> 48 -> 96), each two small matrix products over all threads.
+__device__ void tri_inverse96(const float* Lm, float* X, float* T) {
+  const int tid = threadIdx.x, nt = blockDim.x;
+  for (int w = tid; w < LB * LB; w += nt) X[(w / LB) * LDJ + (w % LB)] = 0.f;
+  __syncthreads();
+  if (tid < LB) {
+    const int b0 = (tid / 12) * 12, j = tid;
+    float x[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) x[i] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+      const int row = b0 + i;
+      float acc = row == j ? 1.f : 0.f;
+#pragma unroll
+      for (int m = 0; m < i; ++m) acc = fmaf(-Lm[row * LDJ + b0 + m], x[m], acc);      // (x[m] = 0 above this column's diagonal)
+      x[i] = row >= j ? acc / Lm[row * LDJ + row] : 0.f;
+      X[row * LDJ + j] = x[i];
+    }
+  }
+  __syncthreads();
+  tri_inverse_level<12>(Lm, X, T);
+  tri_inverse_level<24>(Lm, X, T);
+  tri_inverse_level<48>(Lm, X, T);
+}
+
+// ---- Jacobi, second form: ONE apply pass per round.  The 96 indices sit in 48 adjacent position pairs (2i, 2i+1) and the DATA moves
+// with the round-robin tournament (position 0 fixed, the others shift along the ring top[1..47], bottom[47..0]): a thread owns the
+// 2 x 2 block (pair i) x (pair j), reads it with two aligned 8-byte loads, applies pair i's rotation to its rows and pair j's to its
+// columns and writes the four results to the positions they hold in the NEXT round, into the other buffer -- no tournament-permuted
+// read addresses (round 2: 3-way bank conflicts), no separate row and column passes (3 barriers per round -> 2: rotations, apply).
+// The eigenvector matrix is kept TRANSPOSED and in place, in original index order (row = eigenvector): its two rows of a pair rotate as
+// 48 aligned float2 pairs; which rows those are follows from the closed form of the tournament.  After a whole sweep (95 rounds) every
+// index is back at its own position, so the matrix the caller sees is in original order; the result of an odd number of sweeps sits in
+// the second buffer (returned).
+__device__ __forceinline__ int jr_sigma(int x) {                 // position x's content moves to position sigma(x)
+  if (x == 0) return 0;
+  if (x & 1) return x == 1 ? 2 : x - 2;                           // bottom[i] -> bottom[i-1];  bottom[0] -> top[1]
+  return x < LB - 2 ? x + 2 : LB - 1;                             // top[i] -> top[i+1];  top[47] -> bottom[47]
+}
+__device__ __forceinline__ int jr_pos2idx(int pos, int r) {      // the original index at position pos after r rounds (0 <= r < 95)
+  if (pos == 0) return 0;
+  const int sl = (pos & 1) ? (LB - 2) - (pos >> 1) : (pos >> 1) - 1;      // ring slot: top[i] -> i - 1, bottom[i] -> 94 - i
+  int s0 = sl - r;
+  s0 += s0 < 0 ? LB - 1 : 0;
+  return s0 < LB / 2 - 1 ? 2 * (s0 + 1) : 2 * ((LB - 2) - s0) + 1;
+}
+
+__device__ float* jacobi96(float* A0, float* A1, float* Vt, float2* cs, int2* pq, int* flag, float* dmaxp, int max_sweeps, float rel_tol,
+                           float abs_tol, int* sweeps_out) {
+  constexpr int NT = 1024, NP = LB / 2, NITEM = NP * NP, PER = (NITEM + NT - 1) / NT;      // 2304 blocks / row pairs, 3 per thread
+  const int tid = threadIdx.x;
+  for (int i = tid; i < LB * LB; i += NT) Vt[(i / LB) * LDJ + (i % LB)] = (i / LB) == (i % LB) ? 1.f : 0.f;
+  // A thread's work items are the same in every round (the DATA moves, not the roles): offsets decoded once.  A round is bound by
+  // instruction issue and LDS bandwidth (258 KB through 128 B / clk), so what is left in the loop is loads, 12 + 8 multiply-adds, stores.
+  int a_src[PER], a_d0[PER], a_d1[PER], a_j0[PER], a_j1[PER], a_i[PER], a_j[PER], v_off[PER];
+  bool ok[PER];
+#pragma unroll
+  for (int n = 0; n < PER; ++n) {
+    const int b = tid + n * NT;
+    ok[n] = b < NITEM;
+    const int i = ok[n] ? b / NP : 0, j = ok[n] ? b - i * NP : 0;
+    a_i[n] = i;
+    a_j[n] = j;
+    a_src[n] = (2 * i) * LDJ + 2 * j;
+    a_d0[n] = jr_sigma(2 * i) * LDJ;
+    a_d1[n] = jr_sigma(2 * i + 1) * LDJ;
+    a_j0[n] = jr_sigma(2 * j);
+    a_j1[n] = jr_sigma(2 * j + 1);
+    v_off[n] = 2 * j;                              // (the same decode serves the eigenvector rows: pair i, column pair j)
+  }
+  float* cur = A0;
+  float* nxt = A1;
+  int sweeps = 0;
+  for (int sw = 0; sw < max_sweeps; ++sw) {
+    __syncthreads();
+    if (tid < 64) {
+      float m = 0.f;
+      for (int i = tid; i < LB; i += 64) m = fmaxf(m, fabsf(cur[i * LDJ + i]));
+      m = wave_max(m);
+      if (tid == 0) {
+        *dmaxp = m;
+        *flag = 0;
+      }
+    }
+    __syncthreads();
+    const float floor_abs = abs_tol * *dmaxp;
+    // anything left above the bound?  The same pass puts the mean of a_pq and a_qp in both places: the two are updated by the same
+    // rotations in different operation orders and drift apart by roundoff; a rotation decided on one of them and a convergence test
+    // that reads the other can disagree for ever at the threshold (seen: 12 of 12 sweeps on 3 of 14 batches).
+    bool mine = false;
+    for (int w = tid; w < LB * LB; w += NT) {
+      const int p = w / LB, q = w % LB;
+      if (p < q) {
+        const float m = 0.5f * (cur[p * LDJ + q] + cur[q * LDJ + p]);
+        cur[p * LDJ + q] = m;
+        cur[q * LDJ + p] = m;
+        mine = mine || fabsf(m) > fmaxf(rel_tol * sqrtf(fabsf(cur[p * LDJ + p] * cur[q * LDJ + q])), floor_abs);
+      }
+    }
+    if (mine) *flag = 1;
+    __syncthreads();
+    if (*flag == 0) break;
+    ++sweeps;
+    for (int rd = 0; rd < LB - 1; ++rd) {
+      if (tid < NP) {
+        const int i = tid;
+        const float app = cur[(2 * i) * LDJ + 2 * i], aqq = cur[(2 * i + 1) * LDJ + 2 * i + 1], 
+                    apq = 0.5f * (cur[(2 * i) * LDJ + 2 * i + 1] + cur[(2 * i + 1) * LDJ + 2 * i]);
+        float c = 1.f, s = 0.f;
+        if (fabsf(apq) > fmaxf(rel_tol * sqrtf(fabsf(app * aqq)), floor_abs) && apq != 0.f) {
+          const float tau = (aqq - app) / (2.f * apq);
+          const float t = (tau >= 0.f ? 1.f : -1.f) / (fabsf(tau) + sqrtf(1.f + tau * tau));
+          c = rsqrtf(1.f + t * t);
+          s = t * c;
+        }
+        cs[i] = make_float2(c, s);
+        pq[i] = make_int2(jr_pos2idx(2 * i, rd) * LDJ, jr_pos2idx(2 * i + 1, rd) * LDJ);
+      }
+      __syncthreads();
+#pragma unroll
+      for (int n = 0; n < PER; ++n) {
+        if (!ok[n]) continue;
+        const float2 ri = cs[a_i[n]], rj = cs[a_j[n]];
+        const float2 r0 = *(const float2*)&cur[a_src[n]], r1 = *(const float2*)&cur[a_src[n] + LDJ];
+        const float t0x = ri.x * r0.x - ri.y * r1.x, t0y = ri.x * r0.y - ri.y * r1.y;       // rows: A <- J^T A
+        const float t1x = ri.y * r0.x + ri.x * r1.x, t1y = ri.y * r0.y + ri.x * r1.y;
+        nxt[a_d0[n] + a_j0[n]] = rj.x * t0x - rj.y * t0y;                                     // columns: A <- A J
+        nxt[a_d0[n] + a_j1[n]] = rj.y * t0x + rj.x * t0y;
+        nxt[a_d1[n] + a_j0[n]] = rj.x * t1x - rj.y * t1y;
+        nxt[a_d1[n] + a_j1[n]] = rj.y * t1x + rj.x * t1y;
+        if (ri.y != 0.f) {                                                                    // V <- V J, on the rows of V^T
+          const int2 ii = pq[a_i[n]];
+          float2* vp = (float2*)&Vt[ii.x + v_off[n]];
+          float2* vq = (float2*)&Vt[ii.y + v_off[n]];
+          const float2 x = *vp, yv = *vq;
+          *vp = make_float2(ri.x * x.x - ri.y * yv.x, ri.x * x.y - ri.y * yv.y);
+          *vq = make_float2(ri.y * x.x + ri.x * yv.x, ri.y * x.y + ri.x * yv.y);
+        }
+      }
+      __syncthreads();
+      float* t = cur;
+      cur = nxt;
+      nxt = t;
+    }
+  }
+  __syncthreads();
+  *sweeps_out = sweeps;
+  return cur;
+}
+
+// S f32 [L][96][96] (accumulated by lr_mult_kernel; ZEROED again here for the next stage) -> Cout = D^-1 L^-T with S = D (L L^T) D
+__global__ __launch_bounds__(1024) void lr_orth_kernel(float* __restrict__ Sg, float* __restrict__ Cout) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* B0 = sm;
+  float* B1 = B0 + LB * LDJ;
+  float* B2 = B1 + LB * LDJ;
+  float* d = B2 + LB * LDJ;        // [96]
+  const int tid = threadIdx.x, nt = blockDim.x;
+  float* Sl = Sg + (size_t)blockIdx.x * LB * LB;
+  float* Cl = Cout + (size_t)blockIdx.x * LB * LB;
+  // (S is symmetric up to the order of its atomic additions: the lower triangle as it is.  All nine elements of a thread are
+  // requested before the first is used: a load-use loop would expose nine memory round trips in a kernel that lasts tens of us.)
+  LR_STAMP(1, 0);
+  float sv[9];
+#pragma unroll
+  for (int e = 0; e < 9; ++e) sv[e] = Sl[tid + 1024 * e];
+#pragma unroll
+  for (int e = 0; e < 9; ++e) {
+    const int i = tid + 1024 * e, r = i / LB, c = i % LB;
+    B0[r * LDJ + c] = sv[e];
+    Sl[i] = 0.f;
+  }
+  __syncthreads();
+  if (tid < LB) d[tid] = rsqrtf(fmaxf(B0[tid * LDJ + tid], 1e-30f));
+  __syncthreads();
+#pragma unroll
+  for (int e = 0; e < 9; ++e) {
+    const int i = tid + 1024 * e, r = i / LB, c = i % LB;
+    if (c <= r) B0[r * LDJ + c] = sv[e] * d[r] * d[c];
+  }
+  __syncthreads();
+  LR_STAMP(1, 1);
+  cholesky96(B0, 1e-6f);
+  LR_STAMP(1, 2);
+  tri_inverse96(B0, B1, B2);                     // B1 = L^-1
+  LR_STAMP(1, 3);
+  for (int i = tid; i < LB * LB; i += nt) {
+    const int r = i / LB, c = i % LB;
+    Cl[i] = c >= r ? d[r] * B1[c * LDJ + r] : 0.f;        // C = D^-1 L^-T (upper triangular)
+  }
+  LR_STAMP(1, 4);
+}
+
+// The last stage: P = Y_prev^T Y, S = Y^T Y (both zeroed again here), Cprev = the transform that orthonormalises Y_prev (null: Y_prev is
+// the orthonormal basis itself) -> Cout = W D^-1 L^-T, evals (Ritz values, descending), info[2 l + 1] = Jacobi sweeps run.
+__global__ __launch_bounds__(1024) void lr_ritz_kernel(float* __restrict__ Pg, float* __restrict__ Sg, const float* __restrict__ Cprev,
+                                                       float* __restrict__ Cout, float* __restrict__ evals, int* __restrict__ info,
+                                                       int ritz_sweeps) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* B0 = sm;
+  float* B1 = B0 + LB * LDJ;
+  float* B2 = B1 + LB * LDJ;
+  float* B3 = B2 + LB * LDJ;
+  float* d = B3 + LB * LDJ;        // [96]
+  float* ev = d + LB;              // [96]
+  float2* cs = (float2*)(ev + LB); // [64]
+  int2* pq = (int2*)(cs + 64);     // [64]
+  int* rnk = (int*)(pq + 64);      // [96]
+  int* flag = rnk + LB;
+  float* dmaxp = (float*)(flag + 1);
+  int* swp = (int*)(dmaxp + 1);
+  const int tid = threadIdx.x, nt = blockDim.x;
+  float* Pl = Pg + (size_t)blockIdx.x * LB * LB;
+  float* Sl = Sg + (size_t)blockIdx.x * LB * LB;
+  float* Cl = Cout + (size_t)blockIdx.x * LB * LB;
+  LR_STAMP(2, 0);
+  const bool has_c = Cprev != nullptr;
+  {                                              // all 27 elements of a thread requested before the first is used
+    float pv[9], sv[9], cv[9];
+#pragma unroll
+    for (int e = 0; e < 9; ++e) {
+      pv[e] = Pl[tid + 1024 * e];
+      sv[e] = Sl[tid + 1024 * e];
+      cv[e] = has_c ? Cprev[(size_t)blockIdx.x * LB * LB + tid + 1024 * e] : 0.f;
+    }
+#pragma unroll
+    for (int e = 0; e < 9; ++e) {
+      const int i = tid + 1024 * e, r = i / LB, c = i % LB;
+      (has_c ? B1 : B0)[r * LDJ + c] = pv[e];
+      B3[r * LDJ + c] = sv[e];
+      if (has_c) B2[r * LDJ + c] = cv[e];
+      Pl[i] = 0.f;
+      Sl[i] = 0.f;
+    }
+  }
+  __syncthreads();
+  if (has_c) {
+    mm96<true, false, LDJ>(B2, B1, B0);          // H = C_prev^T P = V^T G V
+    __syncthreads();
+  }
+  for (int i = tid; i < LB * LB; i += nt) {      // symmetrise H and S in place: one thread per unordered pair
+    const int r = i / LB, c = i % LB;
+    if (c < r) {
+      const float h = 0.5f * (B0[r * LDJ + c] + B0[c * LDJ + r]);
+      B0[r * LDJ + c] = h;
+      B0[c * LDJ + r] = h;
+      const float sy = 0.5f * (B3[r * LDJ + c] + B3[c * LDJ + r]);
+      B3[r * LDJ + c] = sy;
+      B3[c * LDJ + r] = sy;
+    }
+  }
+  // off-diagonals below 1e-7 of the largest Ritz value are fp32 noise of the GEMMs that built H: rotating on them never converges
+  LR_STAMP(2, 1);
+  float* Af = jacobi96(B0, B1, B2, cs, pq, flag, dmaxp, ritz_sweeps, 1e-5f, 1e-7f, swp);      // rows of B2 = eigenvectors
+  LR_STAMP(2, 2);
+  if (tid < LB) ev[tid] = Af[tid * LDJ + tid];
+  __syncthreads();
+  if (tid < LB) {                              // rank of each Ritz value (descending, index breaks ties)
+    const float e = ev[tid];
+    int r = 0;
+    for (int j = 0; j < LB; ++j) r += (ev[j] > e) || (ev[j] == e && j < tid);
+    rnk[tid] = r;
+    if (evals) evals[(size_t)blockIdx.x * LB + r] = e;
+  }
+  __syncthreads();
+  for (int i = tid; i < LB * LB; i += nt) {    // B1 = W, columns in Ritz order (eigenvector c is ROW c of B2)
+    const int r = i / LB, c = i % LB;
+    B1[r * LDJ + rnk[c]] = B2[c * LDJ + r];
+  }
+  __syncthreads();
+  mm96<false, false, LDJ>(B3, B1, B0);         // S W
+  __syncthreads();
+  mm96<true, false, LDJ>(B1, B0, B2);          // S' = W^T S W = (Y W)^T (Y W)
+  __syncthreads();
+  if (tid < LB) d[tid] = rsqrtf(fmaxf(B2[tid * LDJ + tid], 1e-30f));
+  __syncthreads();
+  for (int i = tid; i < LB * LB; i += nt) {    // unit diagonal, lower triangle symmetrised
+    const int r = i / LB, c = i % LB;
+    if (c <= r) B0[r * LDJ + c] = 0.5f * (B2[r * LDJ + c] + B2[c * LDJ + r]) * d[r] * d[c];
+  }
+  __syncthreads();
+  LR_STAMP(2, 3);
+  cholesky96(B0, 1e-6f);                       // S'n = L L^T
+  LR_STAMP(2, 4);
+  tri_inverse96(B0, B3, B2);                   // B3 = L^-1 (B2 = S' is dead: scratch)
+  LR_STAMP(2, 5);
+  for (int i = tid; i < LB * LB; i += nt) B1[(i / LB) * LDJ + (i % LB)] *= d[i % LB];      // W D^-1
+  __syncthreads();
+  mm96<false, true, LDJ>(B1, B3, B2);          // C = W D^-1 L^-T
+  __syncthreads();
+  for (int i = tid; i < LB * LB; i += nt) Cl[i] = B2[(i / LB) * LDJ + (i % LB)];
+  if (info && tid == 0) {
+    info[2 * blockIdx.x] = 0;
+    info[2 * blockIdx.x + 1] = *swp;
+  }
+  LR_STAMP(2, 6);
+}
+
+constexpr int ORTH_SMEM = (3 * LB * LDJ + LB) * 4;
+constexpr int RITZ_SMEM = (4 * LB * LDJ + 2 * LB) * 4 + 64 * 8 + 64 * 8 + (LB + 4) * 4;
+inline int lr_mult_smem(int Dt) { return (LR_ROWS * (Dt + 4) + 2 * 32 * LB + LB * LB) * 4; }
+
 constexpr int SMALL_SMEM = (4 * LB * LLD + 2 * LB) * 4 + 64 * 8 + 64 * 8 + (LB + 2) * 4;
 constexpr int JACOBI_SMEM = 2 * NMAX * LD * 4 + 64 * 8 + 64 * 8 + 16;
 
@@ -484,3 +1090,99 @@ extern "C" int dkd_lowrank_step(const float* G, float* V, int32_t L, int32_t Dt,
   DKD_CHECK_LAUNCH("lowrank V = Y C");
   return DKD_OK;
 }
+
+// ---- the chain (see the "round 5" block above)
+namespace {
+struct ChainWs {
+  float *YA, *YB, *S, *P, *C0, *C1;
+  int* info;
+};
+inline int64_t chain_carve(void* ws, int32_t L, int32_t Dt, ChainWs* o) {
+  char* p = (char*)ws;
+  int64_t off = 0;
+  auto take = [&](int64_t bytes) {
+    char* q = p ? p + off : nullptr;
+    off += al256(bytes);
+    return q;
+  };
+  const int64_t y = (int64_t)L * Dt * LB * 4, m = (int64_t)L * LB * LB * 4;
+  char* s0 = take(m);                // S and P first: the part of the workspace that must be zero on entry
+  char* p0 = take(m);
+  char* ya = take(y);
+  char* yb = take(y);
+  char* c0 = take(m);
+  char* c1 = take(m);
+  char* inf = take((int64_t)L * 8);
+  if (o) *o = ChainWs{(float*)ya, (float*)yb, (float*)s0, (float*)p0, (float*)c0, (float*)c1, (int*)inf};
+  return off;
+}
+}  // namespace
+
+extern "C" int64_t dkd_lowrank_chain_workspace_bytes(int32_t L, int32_t Dt) { return chain_carve(nullptr, L, Dt, nullptr); }
+extern "C" int64_t dkd_lowrank_chain_zero_bytes(int32_t L, int32_t Dt) { return 2 * al256((int64_t)L * LB * LB * 4); }
+
+extern "C" int dkd_lowrank_chain(const float* G, float* V, int32_t L, int32_t Dt, int32_t n_mult, int32_t ritz_sweeps, int32_t rank, void* v_hi,
+                                 void* v_lo, float* evals, void* ws, void* stream) {
+  DKD_CHECK_ARG(G && V && ws, "lowrank_chain: null operand");
+  DKD_CHECK_ARG(L > 0 && Dt >= 128 && Dt % 32 == 0 && Dt <= 2048, "lowrank_chain: Dt=%d must be a multiple of 32 in [128, 2048]", Dt);
+  DKD_CHECK_ARG(n_mult >= 1 && n_mult <= 64, "lowrank_chain: n_mult %d", n_mult);
+  DKD_CHECK_ARG(ritz_sweeps >= 0 && ritz_sweeps <= 32, "lowrank_chain: ritz_sweeps %d", ritz_sweeps);
+  DKD_CHECK_ARG(!v_hi || (v_lo && rank > 0 && rank <= LB), "lowrank_chain: hi/lo output needs 0 < rank <= %d", LB);
+  DKD_CHECK_ARG(((uintptr_t)ws & 255) == 0, "lowrank_chain: workspace must be 256-byte aligned");
+  hipStream_t st = as_stream(stream);
+  ChainWs w;
+  chain_carve(ws, L, Dt, &w);
+  const int msm = lr_mult_smem(Dt);
+  int rc = raise_lds(lr_mult_kernel, msm, "lowrank_chain (mult)");
+  if (rc == DKD_OK) rc = raise_lds(lr_orth_kernel, ORTH_SMEM, "lowrank_chain (orth)");
+  if (rc == DKD_OK) rc = raise_lds(lr_ritz_kernel, RITZ_SMEM, "lowrank_chain (ritz)");
+  if (rc != DKD_OK) return rc;
+  // multiplies per stage: 1, 2, 2, ..., (1,) 1
+  int stages[64], ns = 0;
+  if (n_mult == 1) {
+    stages[ns++] = 1;
+  } else {
+    stages[ns++] = 1;
+    int mid = n_mult - 2;
+    while (mid >= 2) {
+      stages[ns++] = 2;
+      mid -= 2;
+    }
+    if (mid) stages[ns++] = 1;
+    stages[ns++] = 1;
+  }
+  const float* src = V;
+  const float* cprev = nullptr;
+  float* cnext = w.C0;
+  const dim3 grid(Dt / LR_ROWS, L);
+  for (int s = 0; s < ns; ++s) {
+    const bool last = s == ns - 1;
+    for (int m = 0; m < stages[s]; ++m) {
+      float* dst = src == w.YA ? w.YB : w.YA;
+      const int flags = ((m == 0 && cprev) ? LR_APPLY_C : 0) | (m == stages[s] - 1 ? LR_GRAM_S : 0) | (last ? LR_GRAM_P : 0);
+      hipLaunchKernelGGL(lr_mult_kernel, grid, dim3(256), msm, st, G, src, cprev, dst, w.S, w.P, Dt, flags);
+      DKD_CHECK_LAUNCH("lowrank_chain Y = (G Y) C");
+      src = dst;
+    }
+    if (!last) {
+      hipLaunchKernelGGL(lr_orth_kernel, dim3(L), dim3(1024), ORTH_SMEM, st, w.S, cnext);
+      DKD_CHECK_LAUNCH("lowrank_chain orthonormalising transform");
+    } else {
+      hipLaunchKernelGGL(lr_ritz_kernel, dim3(L), dim3(1024), RITZ_SMEM, st, w.P, w.S, cprev, cnext, evals, w.info, ritz_sweeps);
+      DKD_CHECK_LAUNCH("lowrank_chain Rayleigh-Ritz stage");
+    }
+    cprev = cnext;
+    cnext = cnext == w.C0 ? w.C1 : w.C0;
+  }
+  const long sV = (long)Dt * LB, sC = (long)LB * LB;
+  hipLaunchKernelGGL((sgemm_kernel<0, 16>), dim3(1, Dt / 16, L), dim3(256), 0, st, src, sV, LB, cprev, sC, LB, V, sV, LB, Dt, LB, LB,
+                     (bf16_t*)v_hi, (bf16_t*)v_lo, rank);
+  DKD_CHECK_LAUNCH("lowrank_chain V = Y C");
+  return DKD_OK;
+}
+
+#ifdef DKD_LR_STAMPS
+extern "C" int dkd_lr_read_stamps(unsigned long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(lr_stamp_buf), sizeof(unsigned long long) * 3 * 64) == hipSuccess ? 0 : -1;
+}
+#endif

@@ -154,6 +154,10 @@ _SIGS = {
     "dkd_lowrank_workspace_bytes": (C.c_int64, [C.c_int32, C.c_int32]),
     "dkd_lowrank_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
                                    C.c_void_p, C.c_void_p, C.c_void_p]),
+    "dkd_lowrank_chain_workspace_bytes": (C.c_int64, [C.c_int32, C.c_int32]),
+    "dkd_lowrank_chain_zero_bytes": (C.c_int64, [C.c_int32, C.c_int32]),
+    "dkd_lowrank_chain": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
+                                    C.c_void_p, C.c_void_p, C.c_void_p]),
     "dkd_adamw_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float,
                                  C.c_float, C.c_float, C.c_float, C.c_int32, C.c_float, C.c_void_p]),
     "dkd_adamw_step_gated": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float,

@@ -450,6 +450,30 @@ def lowrank_step(G, V, mode, ws, rank=0, hi=None, lo=None, evals=None, ritz_swee
     return V
 
 
+def lowrank_chain_workspace(L, Dt, device):
+    """Scratch of ``lowrank_chain`` (zero-initialised: its Gram accumulators must be zero on the first call; every call leaves them so)."""
+    return torch.zeros(lib().dkd_lowrank_chain_workspace_bytes(L, Dt), device=device, dtype=torch.uint8)
+
+
+def lowrank_chain(G, V, n_mult, ritz_sweeps, ws, rank=0, hi=None, lo=None, evals=None):
+    """``n_mult`` power steps from the orthonormal basis V f32 [L, Dt, 96] (in place) and a converged Rayleigh-Ritz step, all layers in
+    the same short launches (include/dkd.h: dkd_lowrank_chain) -- the per-batch solve that stands for model/loss.py:321's svd."""
+    assert G.dtype == F32 and V.dtype == F32 and G.is_contiguous() and V.is_contiguous() and V.shape[2] == 96
+    L, Dt = G.shape[0], G.shape[1]
+    assert G.shape == (L, Dt, Dt) and V.shape[:2] == (L, Dt)
+    if hi is not None:
+        assert hi.dtype == BF16 and lo.dtype == BF16 and hi.is_contiguous() and lo.is_contiguous() and hi.shape == lo.shape == (L, rank, Dt)
+    check(lib().dkd_lowrank_chain(ptr(G), ptr(V), L, Dt, n_mult, ritz_sweeps, rank, ptr(hi), ptr(lo), ptr(evals), ptr(ws), stream()),
+          "lowrank_chain")
+    return V
+
+
+def lowrank_chain_info(ws, L, Dt):
+    """Jacobi sweeps the last ``lowrank_chain`` ran per layer: int32 [L, 2] (column 1) -- diagnostics."""
+    off = lib().dkd_lowrank_chain_workspace_bytes(L, Dt) - (L * 8 + 255) // 256 * 256
+    return ws[off:off + L * 8].view(torch.int32).view(L, 2)
+
+
 def lowrank_info(ws, L, Dt):
     """Jacobi sweeps of the last ``lowrank_step`` per layer: int32 [L, 2] (orthonormalisation, Rayleigh-Ritz) -- diagnostics."""
     off = lib().dkd_lowrank_workspace_bytes(L, Dt) - (L * 8 + 255) // 256 * 256

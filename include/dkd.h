@@ -423,6 +423,21 @@ int64_t dkd_lowrank_workspace_bytes(int32_t L, int32_t Dt);
 int dkd_lowrank_step(const float* G, float* V, int32_t L, int32_t Dt, int32_t mode, int32_t ritz_sweeps, int32_t rank, void* v_hi,
                      void* v_lo, float* evals, void* ws, void* stream);
 
+/* The per-batch solve of the timed path (round 5): `n_mult` power steps of block subspace iteration from the basis V f32 [L, Dt, 96]
+ * (orthonormal on entry: the previous batch's result, or a cold start's), ending in a Rayleigh-Ritz step whose Jacobi diagonalisation
+ * runs until nothing is left to rotate (at most `ritz_sweeps` sweeps) -- n_mult = 8 reproduces torch.linalg.svd's U_k S_k of
+ * model/loss.py:318-326 to fp32 accuracy on changing batches (tests/test_fullsize_gpu.py), n_mult = 1 is round 4's one-step tracker.
+ * A chain of short launches: 16-row panels of Y' = (G Y) C with the previous stage's orthonormalising transform applied to the finished
+ * tile and the 96 x 96 Gram matrices accumulated atomically; one workgroup per layer for the Cholesky / Jacobi stages between them
+ * (multiplies per stage 1, 2, 2, ..., 1).  Outputs as dkd_lowrank_step modes 1 / 3: V in place, evals f32 [L, 96] (may be null),
+ * v_hi / v_lo bf16 [L, rank, Dt] (may be null).  ws: dkd_lowrank_chain_workspace_bytes(L, Dt) bytes, 256-byte aligned, whose first
+ * dkd_lowrank_chain_zero_bytes(L, Dt) bytes must be ZERO when the first call is made (every call leaves them zero again).
+ * Replaces: torch.linalg.svd at model/loss.py:321. */
+int64_t dkd_lowrank_chain_workspace_bytes(int32_t L, int32_t Dt);
+int64_t dkd_lowrank_chain_zero_bytes(int32_t L, int32_t Dt);
+int dkd_lowrank_chain(const float* G, float* V, int32_t L, int32_t Dt, int32_t n_mult, int32_t ritz_sweeps, int32_t rank, void* v_hi,
+                      void* v_lo, float* evals, void* ws, void* stream);
+
 /* ---------------------------------------------------------------- optimizer ([3P] torch.optim.AdamW via timm create_optimizer) */
 /* One launch over a flat parameter segment; optionally refreshes the bf16 shadow copy used by the GEMMs. */
 int dkd_adamw_step(float* p, const float* g, float* m, float* v, void* p_bf16, int64_t n, float lr, float beta1, float beta2,

@@ -276,7 +276,8 @@ def _exact_lowrank(tap, npre, k):
 
 
 def test_lowrank_tracking_at_the_headline_batch(models):
-    """The LRKD targets of the TIMED path: ``LowRankTargets`` with its defaults (one tracking step per batch, <= 2 Jacobi sweeps) instead of
+    """The LRKD targets of the TIMED path: ``LowRankTargets`` with its defaults (round 5: 8 power steps + a converged Rayleigh-Ritz step per
+    batch; the bounds below were set for round 4's one-step tracker and are kept) against
     the reference's exact SVD per batch (model/loss.py:318-326), at the benchmarked size -- batches of 256 through the deit_base_distilled
     teacher, taps of blocks 0, 1, 11, rank 64 -- over a sequence of 24 calls on 4 rotating batches (what bench.py feeds it).  Every call:
     the invariant-subspace residual of the tracked basis (``LowRankTargets.residual``; < 5e-2, measured 7e-3).  Calls 0-5 and every 8th after: against the exact
@@ -386,25 +387,64 @@ def _tracking_errors(sel, tg, npre, k):
     return energy, sv
 
 
-@pytest.mark.parametrize("warm_iters,ritz_sweeps,min_energy,max_sv", [(1, 2, 0.98, 2e-2), (4, 6, 0.999, 2.5e-3)])
-def test_lowrank_tracking_on_fresh_shifting_batches(models, warm_iters, ritz_sweeps, min_energy, max_sv):
-    """the tracker where a real run lives.  24 calls on batches of 256 that NEVER repeat and whose
-    statistics shift between calls (``_shifting_batches``: prototype mixtures of drifting sharpness / contrast / noise), then a deliberate
-    distribution jump (other prototypes, 3 x the contrast) with the residual monitor on (DKD_LRKD_MONITOR=1's setting).
+def _student_features(models_teacher, k):
+    """A randomly initialised DeiT-tiny with the lrkd align modules: what the LRKD term compares the targets with."""
+    from types import SimpleNamespace
+    from deltakd_amd import vit
+    from deltakd_amd.models import attach_aux
+    torch.manual_seed(5)
+    stu = vit.create_model("deit_tiny_patch16_224", num_classes=1000)
+    attach_aux(stu, models_teacher, "lrkd", SimpleNamespace(lrkd_rank=k, dataset="imagenet-1k"))
+    return stu.to(DEV).eval()
 
-    What round 4 measured (profiles/r04_lrkd_tracker_accuracy_vs_cost.txt) and what is therefore asserted -- the i.i.d. rotating batches of
-    the headline-batch test above flatter the tracker, these batches do not:
-      * the defaults of the timed path (one tracking step, <= 2 Jacobi sweeps): captured energy 0.986-0.999 of the optimal rank-64
-        subspace's (asserted >= 0.98), singular values to 1.3e-2 sigma_1 (asserted 2e-2), residual <= 1.6e-2 (asserted 5e-2);
-      * four steps / six sweeps (--lrkd-warm-iters 4 --lrkd-ritz-sweeps 6, +5..7 % step time): energy >= 0.9993 (0.999), singular values
-        to 1.3e-3 (2.5e-3);
-      * --lrkd-exact: the test below.
+
+def _lrkd_term_errors(sel, tg, feats, npre, k, w=(0.2, 0.2, 0.2)):
+    """The LRKD addend  sum_i w_i mse(targets_i, student_i)  (model/loss.py:326-329) computed with the product's targets and with the exact
+    float64 U_k S_k of the same matrices, column signs aligned: relative difference for (a) the given student features, (b) a surrogate
+    of a TRAINED student (features = half the exact target on the columns whose singular value is > 5 % away from both neighbours)."""
+    loss = {"got_random": 0.0, "exact_random": 0.0, "got_trained": 0.0, "exact_trained": 0.0}
+    for li, (tap, got, sf) in enumerate(zip(sel, tg, feats)):
+        ref, S = _exact_lowrank(tap, npre, k)
+        got = got.double()
+        ref = ref * torch.sign((got * ref).sum(0))
+        gap = torch.minimum(S[:k] - S[1:k + 1], torch.cat([S[:1] * 1e9, S[:k - 1] - S[1:k]])) / S[:k]
+        trained = 0.5 * ref * (gap > 0.05)
+        loss["got_random"] += w[li] * ((got - sf) ** 2).mean().item()
+        loss["exact_random"] += w[li] * ((ref - sf) ** 2).mean().item()
+        loss["got_trained"] += w[li] * ((got - trained) ** 2).mean().item()
+        loss["exact_trained"] += w[li] * ((ref - trained) ** 2).mean().item()
+    return (abs(loss["got_random"] - loss["exact_random"]) / loss["exact_random"],
+            abs(loss["got_trained"] - loss["exact_trained"]) / loss["exact_trained"])
+
+
+TERM_TOL = 1e-2          # tests/test_parity_gpu.py: every addend of a loss within 1 % of the reference's
+
+
+@pytest.mark.parametrize("mode,min_energy,max_sv,max_term", [("default", 0.9999, 5e-4, 1e-3), ("fast", 0.98, 2e-2, 3e-2)])
+def test_lowrank_tracking_on_fresh_shifting_batches(models, mode, min_energy, max_sv, max_term):
+    """The LRKD targets where a real run lives: 24 calls on batches of 256 that NEVER repeat and whose statistics shift between calls
+    (``_shifting_batches``: prototype mixtures of drifting sharpness / contrast / noise), then a deliberate distribution jump (other
+    prototypes, 3 x the contrast) with the residual monitor on (DKD_LRKD_MONITOR=1's setting).  Against the exact float64 decomposition
+    of each batch's own matrices (what model/loss.py:318-326 computes):
+
+      * ``default`` = ``LowRankTargets()`` as bench.py and tools/train.py build it (round 5: 8 power steps + a converged Rayleigh-Ritz
+        step on every batch, ``LowRankTargets.EXACT``): energy >= 0.9999 of the optimal rank-64 subspace's (measured 0.99994), singular
+        values to 5e-4 sigma_1 (2.2e-4), and -- VERDICT round 4, item 1(a) -- the LRKD ADDEND ITSELF, computed with these targets and
+        with the exact ones (signs aligned) for a randomly initialised student and for a trained-student surrogate, within 1e-3
+        (measured 6e-5), i.e. ten times inside ``TERM_TOL`` = 1e-2, the bound every addend of every loss has to meet;
+      * ``fast`` = ``--lrkd-fast`` (round 4's default: one tracking step, <= 2 Jacobi sweeps): energy 0.986-0.999, singular values to
+        1.3e-2 sigma_1, LRKD addend off by up to 1.4e-2 -- OUTSIDE ``TERM_TOL``, which is why it is no longer the default; asserted at
+        its measured class so that a regression of the opt-in mode still shows.
     After the jump the basis the call RETURNS is inside the residual bound whatever the first residual on the new distribution was."""
     from deltakd_amd.losses import LowRankTargets
     t = models
     k, npre = 64, 2
-    solver = LowRankTargets(warm_iters=warm_iters, ritz_sweeps=ritz_sweeps)
-    worst = dict(energy=1.0, sv=0.0, residual=0.0)
+    solver = LowRankTargets() if mode == "default" else LowRankTargets(**LowRankTargets.FAST)
+    if mode == "default":
+        assert (solver.warm_iters, solver.ritz_sweeps) == (LowRankTargets.EXACT["warm_iters"], LowRankTargets.EXACT["ritz_sweeps"]), \
+            "the default mode must be the converge-every-batch setting"
+    stu = _student_features(t, k)
+    worst = dict(energy=1.0, sv=0.0, residual=0.0, term_random=0.0, term_trained=0.0)
     n, jump = 28, 24
     for call, x in enumerate(_shifting_batches(n, seed=123, jump_at=jump)):
         if call == jump:
@@ -422,11 +462,20 @@ def test_lowrank_tracking_on_fresh_shifting_batches(models, warm_iters, ritz_swe
         worst["residual"] = max(worst["residual"], res)
         if 1 <= call <= 7 or call % 4 == 0 and call > 0:
             energy, sv = _tracking_errors(sel, tg, npre, k)
+            with torch.no_grad():
+                _, staps = stu.forward_with_taps(x, (0, 1, 11))
+                feats = [stu.align[i](staps[b][:, 1:]).reshape(-1, k).double() for i, b in enumerate((0, 1, 11))]
+            d_r, d_t = _lrkd_term_errors(sel, tg, feats, npre, k)
             worst["energy"], worst["sv"] = min(worst["energy"], energy), max(worst["sv"], sv)
-            print(f"call {call}: energy {energy:.5f}, singular values to {sv:.2e} sigma_1, residual {res:.2e}")
-    print(f"warm_iters {warm_iters}, ritz_sweeps {ritz_sweeps}: worst over the never-repeating, shifting sequence:", worst,
+            worst["term_random"], worst["term_trained"] = max(worst["term_random"], d_r), max(worst["term_trained"], d_t)
+            print(f"call {call}: energy {energy:.5f}, singular values to {sv:.2e} sigma_1, residual {res:.2e}; LRKD addend vs exact targets: "
+                  f"random student {d_r:.2e}, trained-student surrogate {d_t:.2e}")
+    print(f"{mode} (warm_iters {solver.warm_iters}, ritz_sweeps {solver.ritz_sweeps}): worst over the never-repeating, shifting sequence:", worst,
           "re-converged after the jump:", solver.reconverged)
     assert worst["residual"] < 5e-2 and worst["energy"] > min_energy and worst["sv"] < max_sv, worst
+    assert worst["term_random"] < max_term and worst["term_trained"] < max_term, worst
+    if mode == "default":
+        assert max_term <= TERM_TOL / 10
     assert solver.reconverged <= n - jump
 
 
@@ -434,8 +483,8 @@ def test_lowrank_converge_every_batch_is_the_reference_exact_mode(models):
     """Item 4(b): ``--lrkd-exact`` (= --lrkd-warm-iters 8 --lrkd-ritz-sweeps 12, ``LowRankTargets.EXACT``) converges the basis on EVERY
     batch instead of tracking it -- the setting that stands for the reference's per-batch ``torch.linalg.svd`` (model/loss.py:318-326).
     On fresh shifting batches of 256 it must reproduce the exact decomposition an order of magnitude tighter than the tracking bounds:
-    energy >= 0.9998 (measured 0.99994), singular values to 5e-4 sigma_1 (2.2e-4), residual < 1e-2 (7e-4); DKD_LRKD_EXACT=1 python bench.py
-    times it: +14 % step time with the chain on its own stream and two batches of lookahead (profiles/r04_lrkd_tracker_accuracy_vs_cost.txt)."""
+    energy >= 0.9998 (measured 0.99994), singular values to 5e-4 sigma_1 (2.2e-4), residual < 1e-2 (7e-4).  Since round 5 this IS the
+    default of bench.py / tools/train.py (dkd_lowrank_chain: +1.9 % step time against --lrkd-fast on the same box; round 4: +14 %)."""
     from deltakd_amd.losses import LowRankTargets
     t = models
     k, npre = 64, 2

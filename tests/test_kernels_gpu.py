@@ -607,6 +607,72 @@ def test_lowrank_step_kernels(ops, Dt):
         assert ((V2[l].double().cpu().t() @ q[:, :r]) ** 2).sum().item() > r - 1e-2
 
 
+@pytest.mark.parametrize("Dt", [768, 384, 1024, 128])
+def test_lowrank_chain(ops, Dt):
+    """dkd_lowrank_chain (csrc/lowrank.hip, the per-batch solve of the timed path) against float64 eigh of the same matrices: from a
+    basis rotated away from the eigenvectors (a random rotation of 0.2 rad per coordinate pair inside the span and a perturbation out of
+    it), n_mult power steps + the converged Rayleigh-Ritz step must return the leading eigenpairs -- values to 2e-5 lambda_1 after 12
+    steps, sorted, vectors of the separated part of the spectrum up to sign, an orthonormal basis to fp32 roundoff, hi + lo = V_k^T --
+    for every multiply schedule (n_mult 1, 2, 3, 4, 5, 8, 12: stages of 1 and 2 multiplies), reading ONLY the tiles of G on and above
+    the diagonal (the rest is NaN), and leaving its Gram accumulators zero for the next call."""
+    L, b, r = 3, 96, min(64, Dt // 2)
+    g = torch.Generator().manual_seed(5)
+    Gs, refs = [], []
+    for l in range(L):
+        q = torch.linalg.qr(torch.randn(Dt, Dt, generator=g, dtype=torch.float64))[0]
+        lam = torch.cat([torch.linspace(50, 8, 40, dtype=torch.float64), 6.0 * torch.exp(-torch.arange(Dt - 40, dtype=torch.float64) / 25.0) + 0.05])
+        refs.append((lam, q))
+        Gs.append(((q * lam) @ q.t()).float())
+    G = torch.stack(Gs).to(dev())
+    blk = torch.arange(Dt, device=dev()) // 128
+    Gu = torch.where((blk[:, None] > blk[None, :])[None], torch.full_like(G, float("nan")), G).contiguous()
+    ws = ops.lowrank_chain_workspace(L, Dt, G.device)
+    nz = ops.lib().dkd_lowrank_chain_zero_bytes(L, Dt)
+    eye = torch.eye(b, device=dev()).expand(L, b, b)
+    hi = torch.empty(L, r, Dt, device=dev(), dtype=BF16)
+    lo = torch.empty(L, r, Dt, device=dev(), dtype=BF16)
+    ev = torch.empty(L, b, device=dev())
+
+    def start(seed):
+        """the exact leading eigenvectors, mixed among themselves and tilted out of their span: orthonormal, not converged"""
+        gg = torch.Generator().manual_seed(seed)
+        out = []
+        for l in range(L):
+            q = refs[l][1]
+            mix = torch.linalg.qr(torch.eye(b, dtype=torch.float64) + 0.2 * torch.randn(b, b, generator=gg, dtype=torch.float64))[0]
+            v = q[:, :b] @ mix + 0.05 * torch.randn(Dt, b, generator=gg, dtype=torch.float64) / Dt ** 0.5
+            out.append(torch.linalg.qr(v)[0].float())
+        return torch.stack(out).to(dev()).contiguous()
+
+    for n_mult in (1, 2, 3, 4, 5, 8, 12):
+        V = start(100 + n_mult)
+        ops.lowrank_chain(Gu, V, n_mult, 12, ws, rank=r, hi=hi, lo=lo, evals=ev)
+        assert torch.isfinite(V).all() and torch.isfinite(ev).all(), n_mult
+        assert int(ws[:nz].view(torch.int32).abs().max()) == 0, "the Gram accumulators must be left zero"
+        close(V.transpose(1, 2) @ V, eye, 1e-4, f"n_mult {n_mult}: orthonormal basis")
+        sweeps = int(ops.lowrank_chain_info(ws, L, Dt)[:, 1].max())
+        assert 1 <= sweeps <= 12, sweeps
+        for l in range(L):
+            lam, q = refs[l]
+            assert (ev[l, 1:] <= ev[l, :-1] + 1e-6 * ev[l, 0]).all(), "Ritz values not sorted"
+            Vl = V[l].double().cpu()
+            # Ritz values = Rayleigh quotients of the returned vectors' predecessors: within the iteration's convergence of the eigenvalues
+            tol = {1: 3e-2, 2: 1e-2, 3: 5e-3, 4: 2e-3, 5: 1e-3, 8: 2e-4, 12: 2e-5}[n_mult]
+            assert (ev[l, :r].double().cpu() - lam[:r]).abs().max().item() <= tol * lam[0].item(), (n_mult, l)
+            Vt = V[l, :, :r].t()
+            close(hi[l].float() + lo[l].float(), Vt, 1e-4, "hi + lo")
+            assert torch.equal(hi[l], Vt.to(BF16))
+            if n_mult >= 8:
+                lead = min(40, r)                   # the well-separated leading eigenvectors, up to sign
+                dots = (Vl[:, :lead] * q[:, :lead]).sum(0).abs()
+                assert dots.min().item() > 1 - 1e-3, (n_mult, l, dots.min().item())
+                assert ((Vl[:, :r].t() @ q[:, :r]) ** 2).sum().item() > r - 1e-2
+    # a second call on the same matrices from the converged basis: one sweep or none, same answer (signs continuous)
+    V1 = V.clone()
+    ops.lowrank_chain(Gu, V, 2, 12, ws, evals=ev)
+    close((V[:, :, :32] * V1[:, :, :32]).sum(1), torch.ones(L, 32, device=dev()), 1e-3, "warm restart keeps vectors and signs")
+
+
 def test_lowrank_targets_vs_svd(ops):
     """Dt = 768 (subspace iteration + Rayleigh-Ritz path): U_k S_k against torch.linalg.svd on the host, up to column sign.
     Cold start, then a warm-started call on a different batch drawn from the same feature distribution."""

@@ -35,9 +35,11 @@ for wi, rs in settings:
             got = got.double()
             energy = min(energy, ((got ** 2).sum() / (S[:k] ** 2).sum()).item())
             sv = max(sv, ((got.norm(dim=0) - S[:k]).abs() / S[0]).max().item())
-        rows.append((energy, sv, res, dt))
+        from deltakd_amd import ops as _ops
+        sweeps = int(_ops.lowrank_chain_info(solver._cws, 3, 768)[:, 1].max()) if getattr(solver, "_cws", None) is not None else -1
+        rows.append((energy, sv, res, dt, sweeps))
     print(f"warm_iters {wi} ritz_sweeps {rs}: ms/call (host-synced) {sum(r[3] for r in rows[2:]) / (n - 2):.2f}")
     for call, r in enumerate(rows):
-        print(f"   call {call:2d}{' (jump)' if call >= n - 3 else ''}: energy {r[0]:.5f}  sv {r[1]:.2e}  residual {r[2]:.2e}")
+        print(f"   call {call:2d}{' (jump)' if call >= n - 3 else ''}: energy {r[0]:.5f}  sv {r[1]:.2e}  residual {r[2]:.2e}  jacobi sweeps {r[4]}")
     S = exact[1][0]
 print("spectrum of tap 0, call 1: sigma_1..4, 32, 64, 65, 96 / sigma_1:", [round((S[i] / S[0]).item(), 4) for i in (0, 1, 2, 3, 31, 63, 64, 95)])

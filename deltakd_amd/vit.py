@@ -412,6 +412,12 @@ def wgrad_group_size(model):
     return max(1, min(WGRAD_GROUP_MAX, g))
 
 
+def _in_backward_pass():
+    """Is the autograd engine executing a graph task on this thread?  (torch._C._current_graph_task_id() is -1 outside one.)"""
+    fn = getattr(torch._C, "_current_graph_task_id", None)
+    return fn is not None and fn() != -1
+
+
 def flush_wgrads(model):
     """Launch the weight gradients deferred so far (no-op when there are none) and report their blocks to the data-parallel hook."""
     rt = _rt(model)
@@ -883,10 +889,15 @@ class VisionTransformer(nn.Module):
         if grad:
             stale = _rt(self).get("wgrad_pending")
             if stale:
-                # weight gradients of up to six blocks wait for their grouped launch: a grad-mode forward in the MIDDLE of a backward
-                # pass (activation-checkpoint recompute, a forward inside a hook) must not lose them -- flush first.  After a backward
-                # pass that died half-way they are garbage the next zero_grad() clears anyway.
-                flush_wgrads(self)
+                # weight gradients of up to six blocks wait for their grouped launch.  A grad-mode forward in the MIDDLE of a backward
+                # pass (activation-checkpoint recompute, a forward inside a hook: the autograd engine is executing a graph task on this
+                # thread) must not lose them -- flush first.  Outside a backward pass they are what a pass that died half-way left
+                # behind: DROPPED, not flushed -- a loop that calls zero_grad() BEFORE the forward would otherwise get the aborted
+                # pass's partial weight gradients added into the next step.
+                if _in_backward_pass():
+                    flush_wgrads(self)
+                else:
+                    _rt(self)["wgrad_pending"] = []
             x = _EmbedFn.apply(self.pos_embed, self, img)
             for i in range(depth):
                 x, tap = _BlockFn.apply(x, self, i, B, N, scales[2 * i], scales[2 * i + 1], i in want)

@@ -31,7 +31,7 @@ class Recorder:
 
 CASES = [  # kind, student width (0 = the real architectures), epochs, batches per epoch, window
     pytest.param("mgd", 64, 3, 20, 10, id="mgd-64-60steps"),
-    pytest.param("lrkd", 64, 3, 20, 10, id="lrkd-64-60steps"),
+    pytest.param("lrkd", 64, 4, 30, 10, id="lrkd-64-120steps"),      # (back at 120 steps: the headline branch -- ADVICE round 4)
     pytest.param("mgd", 192, 4, 30, 10, id="mgd-192-120steps"),
     # BASELINE config 2 at its real width: deit_tiny_distilled <- deit_small_distilled, soft, 224 x 224, 1000 classes, through the fused
     # D = 192 kernels; 3 epochs x 10 batches of 8 = 30 free-running steps (tools/train.py:318-334).  `-m "gpu and not real_curve"` skips it.
@@ -41,8 +41,8 @@ CASES = [  # kind, student width (0 = the real architectures), epochs, batches p
 
 @pytest.mark.parametrize("kind,width,epochs,n_batches,win", CASES)
 def test_loss_curve_tracks_the_oracle_loop(kind, width, epochs, n_batches, win):
-    """(60 steps for the 64-wide pairs -- round 3 ran 120 on all three: the suite's time went there --, 120 for the 192-wide student
-    that takes the fused kernels, 30 for the real architectures.)  Asserted (the measured values are in the assertion messages / printed):
+    """(60 steps for the 64-wide mgd pair, 120 for the 64-wide lrkd pair -- the headline branch -- and for the 192-wide student that takes
+    the fused kernels, 30 for the real architectures.)  Asserted (the measured values are in the assertion messages / printed):
       * the loss averaged over windows of 10 steps, at all 12 windows: product within 0.5 % of the oracle's (measured: 0.05 %);
       * the curves are curves: the oracle's last window is well below its first (the toy problem is learning, so an all-constant
         loss could not pass), and the product's per-epoch ``train_loss`` (what train_one_epoch returns) follows the oracle's to 0.5 %;

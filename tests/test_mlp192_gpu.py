@@ -260,3 +260,47 @@ def test_deferred_weight_gradients_equal_the_per_block_launches(group, monkeypat
         for n in ref:
             err = (got[n] - ref[n]).norm().item() / (ref[n].norm().item() + 1e-20)
             assert err <= 2e-5, (partial, n, err)
+
+
+def test_aborted_backward_does_not_leak_into_the_next_step(monkeypatch):
+    """a backward pass that dies half-way leaves deferred weight gradients pending.  The next grad-mode forward must DROP
+    them (it runs outside any backward pass), not flush them into .grad: a zero_grad() -> forward -> backward loop would otherwise add
+    the aborted pass's partial gradients to the next step.  (A forward INSIDE a backward pass still flushes: vit._in_backward_pass.)"""
+    from deltakd_amd import vit
+    monkeypatch.setenv("DKD_WGRAD_GROUP", "6")
+    torch.manual_seed(3)
+    m = vit.VisionTransformer(192, 5, 3, 10, False, 0.0, img_size=64, patch_size=16).to(dev()).train()
+    img = torch.randn(6, 3, 64, 64, device=dev(), generator=torch.Generator(device=dev()).manual_seed(9))
+    real = vit._block_backward
+    state = {"abort": True}
+
+    def dying(g, gtap, model, blk, saved, idx=None):
+        if state["abort"] and idx == 2:
+            raise RuntimeError("boom")                  # blocks 4 and 3 have run their backward and deferred their weight gradients
+        return real(g, gtap, model, blk, saved, idx)
+    monkeypatch.setattr(vit, "_block_backward", dying)
+    with pytest.raises(RuntimeError, match="boom"):
+        m(img).float().square().mean().backward()
+    torch.cuda.synchronize()
+    assert vit._rt(m).get("wgrad_pending"), "the aborted pass should have left deferred weight gradients behind (else this test tests nothing)"
+    state["abort"] = False
+    for p in m.parameters():                            # zero_grad FIRST, then forward: the order the advisor named
+        if p.grad is not None:
+            p.grad.zero_()
+    m(img).float().square().mean().backward()
+    torch.cuda.synchronize()
+    assert not vit._rt(m).get("wgrad_pending")
+    got = {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}
+    torch.manual_seed(3)                                # reference: the same step on a fresh copy of the model
+    m2 = vit.VisionTransformer(192, 5, 3, 10, False, 0.0, img_size=64, patch_size=16).to(dev()).train()
+    m2.load_state_dict(m.state_dict())
+    m2(img).float().square().mean().backward()
+    torch.cuda.synchronize()
+    checked = 0
+    for n, p in m2.named_parameters():
+        if p.grad is None:
+            continue
+        err = (got[n] - p.grad).norm().item() / (p.grad.norm().item() + 1e-20)
+        assert err <= 2e-5, (n, err)
+        checked += 1
+    assert checked > 40

@@ -237,6 +237,42 @@ __global__ void ema_kernel(float* __restrict__ ema, const float* __restrict__ p,
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) ema[i] = d * ema[i] + (1.f - d) * p[i];
 }
 
+// ---- the glue that used to be ATen launches on the step
+// x (bf16, n8 groups of 8) *= *s, the product formed in f32: the upstream scalar of an align term's backward arrives as a device tensor.
+__global__ void scale_bf16_kernel(bf16_t* __restrict__ x, const float* __restrict__ s, long n8) {
+  const float f = *s;
+  for (long t = blockIdx.x * (long)blockDim.x + threadIdx.x; t < n8; t += (long)gridDim.x * blockDim.x) {
+    uint4 v = *(const uint4*)(x + t * 8);
+    uint32_t* w = (uint32_t*)&v;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) w[i] = pack2bf(__uint_as_float(w[i] << 16) * f, __uint_as_float(w[i] & 0xffff0000u) * f);
+    *(uint4*)(x + t * 8) = v;
+  }
+}
+// dst bf16 [rows, Cp] = bf16(src f32 [rows, C] (row stride lds) * (*scalar or 1)), columns C .. Cp zero (the K padding of the head's dgrad)
+__global__ void cast_pad_kernel(const float* __restrict__ src, int lds, const float* __restrict__ scalar, bf16_t* __restrict__ dst, int rows,
+                                int C, int Cp) {
+  const float f = scalar ? *scalar : 1.f;
+  const long total = (long)rows * Cp;
+  for (long t = blockIdx.x * (long)blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+    const int r = (int)(t / Cp), c = (int)(t % Cp);
+    dst[t] = c < C ? f2bf(src[(size_t)r * lds + c] * f) : (bf16_t)0;
+  }
+}
+// DropPath: out[i, b] = (u < keep[i]) / keep[i] with u ~ U[0, 1) from a counter-based generator (splitmix64 of seed and element index):
+// timm's x.new_empty(shape).bernoulli_(keep_prob) / keep_prob for all 2 x depth branches of a step in one launch.
+__global__ void droppath_scales_kernel(float* __restrict__ out, const float* __restrict__ keep, int n, int B, unsigned long long seed) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n * B) return;
+  unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (unsigned long long)(t + 1);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z ^= z >> 31;
+  const float u = (float)(z >> 40) * (1.f / 16777216.f);          // 24 bits
+  const float k = keep[t / B];
+  out[t] = u < k ? 1.f / k : 0.f;
+}
+
 inline int grid_for(long work, int block = 256, int cap = 4096) {
   long g = (work + block - 1) / block;
   return (int)(g < 1 ? 1 : (g > cap ? cap : g));
@@ -374,5 +410,30 @@ extern "C" int dkd_ema_update(float* ema, const float* p, int64_t n, float decay
   DKD_CHECK_ARG(ema && p && n > 0, "ema_update: bad arguments");
   hipLaunchKernelGGL(ema_kernel, dim3(grid_for(n, 256, 8192)), dim3(256), 0, as_stream(stream), ema, p, (long)n, decay);
   DKD_CHECK_LAUNCH("ema_update");
+  return DKD_OK;
+}
+
+extern "C" int dkd_scale_bf16(void* x, const float* scalar_dev, int64_t n, void* stream) {
+  DKD_CHECK_ARG(x && scalar_dev && n >= 0 && n % 8 == 0 && ((uintptr_t)x & 15) == 0, "scale_bf16: n must be a multiple of 8, x 16-byte aligned");
+  if (n == 0) return DKD_OK;
+  hipLaunchKernelGGL(scale_bf16_kernel, dim3(grid_for(n / 8)), dim3(256), 0, as_stream(stream), (bf16_t*)x, scalar_dev, (long)(n / 8));
+  DKD_CHECK_LAUNCH("scale_bf16");
+  return DKD_OK;
+}
+
+extern "C" int dkd_cast_pad_bf16(const float* src, int32_t ld_src, const float* scalar_dev, void* dst, int32_t rows, int32_t C, int32_t Cp,
+                                 void* stream) {
+  DKD_CHECK_ARG(src && dst && rows > 0 && C > 0 && Cp >= C && ld_src >= C, "cast_pad_bf16: bad shape");
+  hipLaunchKernelGGL(cast_pad_kernel, dim3(grid_for((long)rows * Cp)), dim3(256), 0, as_stream(stream), src, ld_src, scalar_dev, (bf16_t*)dst,
+                     rows, C, Cp);
+  DKD_CHECK_LAUNCH("cast_pad_bf16");
+  return DKD_OK;
+}
+
+extern "C" int dkd_droppath_scales(float* out, const float* keep_prob, int32_t n, int32_t B, uint64_t seed, void* stream) {
+  DKD_CHECK_ARG(out && keep_prob && n > 0 && B > 0, "droppath_scales: bad shape");
+  hipLaunchKernelGGL(droppath_scales_kernel, dim3(cdiv(n * B, 256)), dim3(256), 0, as_stream(stream), out, keep_prob, n, B,
+                     (unsigned long long)seed);
+  DKD_CHECK_LAUNCH("droppath_scales");
   return DKD_OK;
 }

@@ -113,10 +113,17 @@ class _AlignTermFn(torch.autograd.Function):
     def backward(ctx, g):
         B, N, Ds, npre, M, Dt, Kp = ctx.dims
         align, da = ctx.align, ctx.da
-        da.mul_(g)          # 0-dim f32 factor: the product is formed in f32, not with a bf16-rounded factor
+        # the upstream factor is a 0-dim f32 DEVICE tensor: the product is formed in f32 by one small kernel (ATen's bf16 x f32-scalar
+        # multiply took 30 us per term at this size)
+        if da.numel() % 8 == 0 and g.dtype == F32 and g.is_cuda:
+            ops.scale_bf16_(da, g.reshape(1))
+        else:
+            da.mul_(g)
         smap = strip_map(N, npre)
         ops.gemm_tn(da, ctx.tap2, ensure_grad(align.weight), M=M, N1=Dt, bmap=smap, colsum=ensure_grad(align.bias))
-        dtap = torch.zeros(B * N, Ds, device=da.device, dtype=BF16)
+        dtap = torch.empty(B * N, Ds, device=da.device, dtype=BF16)
+        if npre:
+            dtap.view(B, N, Ds)[:, :npre].zero_()      # (the GEMM below writes every patch row; only the prefix rows need zeros)
         ops.gemm_nt(da, ctx.shadow.get(align.weight, transposed=True, pad_k_to=Kp), out=dtap, cmap=smap)
         ctx.da = ctx.tap2 = None
         return dtap.view(B, N, Ds), None, None, None, None

@@ -305,6 +305,30 @@ def scale_cast_bf16(x, *, M=None, xmap=IDENT, rowscale=None, rows_per_sample=0, 
     return y
 
 
+def scale_bf16_(x, scalar):
+    """x (bf16, contiguous, numel % 8 == 0) *= scalar (0-dim / 1-element f32 DEVICE tensor), in place, product formed in f32."""
+    assert x.dtype == BF16 and x.is_contiguous() and scalar.dtype == F32 and scalar.numel() == 1
+    check(lib().dkd_scale_bf16(ptr(x), ptr(scalar), x.numel(), stream()), "scale_bf16")
+    return x
+
+
+def cast_pad_bf16(src, Cp, scalar=None):
+    """src f32 [rows, C] (unit column stride) -> bf16 [rows, Cp], columns C.. zero; optionally times a 1-element f32 device tensor."""
+    assert src.dtype == F32 and src.dim() == 2 and src.stride(1) == 1
+    rows, Cc = src.shape
+    out = torch.empty(rows, Cp, device=src.device, dtype=BF16)
+    check(lib().dkd_cast_pad_bf16(ptr(src), src.stride(0), ptr(scalar), ptr(out), rows, Cc, Cp, stream()), "cast_pad_bf16")
+    return out
+
+
+def droppath_scales(keep_prob, B, seed):
+    """keep_prob f32 [n] (device) -> f32 [n, B]: Bernoulli(keep_prob[i]) / keep_prob[i] per sample, one launch for all branches."""
+    n = keep_prob.numel()
+    out = torch.empty(n, B, device=keep_prob.device, dtype=F32)
+    check(lib().dkd_droppath_scales(ptr(out), ptr(keep_prob), n, B, int(seed) & (2 ** 64 - 1), stream()), "droppath_scales")
+    return out
+
+
 def cast_weight(w, w_bf16=None, w_t_bf16=None):
     """w f32 [rows, cols] (contiguous) -> bf16 copy and/or bf16 transpose, written into the given buffers."""
     assert w.dtype == F32 and w.is_contiguous()

@@ -412,6 +412,31 @@ def wgrad_group_size(model):
     return max(1, min(WGRAD_GROUP_MAX, g))
 
 
+# The student and the teacher of a step embed the SAME mixed batch with the same patch size (tools/engine.py:37,48: the criterion is given
+# the samples the student saw): the bf16 patch matrix [B * 196, 768] is gathered once per batch and shared -- the second model to ask
+# (the student, a batch of lookahead later) waits on the event of the stream that produced it.  Keyed by the tensor OBJECT and its
+# version counter, held weakly: a new batch, or the same storage rewritten in place, gathers again.  DKD_NO_SHARED_PATCHES=1 disables.
+_PATCH_CACHE = weakref.WeakKeyDictionary()
+
+
+def _shared_patches(img, p):
+    if os.environ.get("DKD_NO_SHARED_PATCHES"):
+        return ops.im2col_patches(img, p)
+    cur = torch.cuda.current_stream(img.device)
+    hit = _PATCH_CACHE.get(img)
+    if hit is not None and hit[0] == (img._version, p, img.data_ptr()):
+        _, patches, ev, st = hit
+        if st != cur.cuda_stream:
+            cur.wait_event(ev)
+            patches.record_stream(cur)
+        return patches
+    patches = ops.im2col_patches(img, p)
+    ev = torch.cuda.Event()
+    ev.record(cur)
+    _PATCH_CACHE[img] = ((img._version, p, img.data_ptr()), patches, ev, cur.cuda_stream)
+    return patches
+
+
 def _in_backward_pass():
     """Is the autograd engine executing a graph task on this thread?  (torch._C._current_graph_task_id() is -1 outside one.)"""
     fn = getattr(torch._C, "_current_graph_task_id", None)
@@ -781,8 +806,7 @@ class _HeadFn(torch.autograd.Function):
         for t, hd in enumerate(heads):
             if gz[t] is None:
                 continue
-            dz = torch.zeros(B, Cp, device=x.device, dtype=BF16)
-            dz[:, :C] = gz[t]
+            dz = ops.cast_pad_bf16(gz[t].float() if gz[t].stride(-1) == 1 else gz[t].float().contiguous(), Cp)       # (one launch: zeros + strided cast-copy were two)
             ops.gemm_tn(dz, y, ensure_grad(hd.weight), M=B, N1=C, bmap=RowMap(1, npre, t), colsum=ensure_grad(hd.bias))
             # d y[b, t, :] = dz[b, :] @ W  (NT against the K-padded W^T shadow), scattered to row b*npre + t
             ops.gemm_nt(dz, m._shadow.get(hd.weight, transposed=True, pad_k_to=Cp), out=dy, cmap=RowMap(1, npre, t))
@@ -856,9 +880,11 @@ class VisionTransformer(nn.Module):
         # with a stream synchronise -- the host could never run ahead of the GPU across a step boundary)
         kp = _rt(self).get("keep_prob")
         if kp is None or kp[0] != (tuple(probs), device):
-            kp = _rt(self)["keep_prob"] = ((tuple(probs), device), 1.0 - torch.tensor(probs, device=device, dtype=F32)[:, None])
-        keep_prob = kp[1]
-        scale = (torch.rand(len(probs), B, device=device) < keep_prob).to(F32) / keep_prob
+            kp = _rt(self)["keep_prob"] = ((tuple(probs), device), (1.0 - torch.tensor(probs, device=device, dtype=F32)).contiguous())
+        # ONE launch for the 2 x depth masks of a step (rand + lt + cast + div were four): a counter-based generator on the device,
+        # seeded per step from torch's CPU generator (torch.manual_seed covers it; drawing the seed launches nothing)
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+        scale = ops.droppath_scales(kp[1], B, seed)
         return [None if p == 0.0 else scale[i] for i, p in enumerate(probs)]
 
     def _embed(self, img):
@@ -868,7 +894,7 @@ class VisionTransformer(nn.Module):
         B = img.shape[0]
         N, D, npre = self.num_tokens, self.embed_dim, self.num_prefix_tokens
         P = N - npre
-        patches = ops.im2col_patches(img, self.patch_embed.patch_size)
+        patches = _shared_patches(img, self.patch_embed.patch_size)
         x = torch.empty(B * N, D, device=img.device, dtype=F32)
         pos = self.pos_embed.view(N, D)
         ops.gemm_nt(patches, self._shadow.get(self.patch_embed.proj.weight), out=x, bias=self.patch_embed.proj.bias,

@@ -401,6 +401,17 @@ int64_t dkd_block_fwd_workspace_bytes(int32_t B, int32_t N, int32_t D, int32_t H
 int64_t dkd_block_bwd_workspace_bytes(int32_t B, int32_t N, int32_t D, int32_t hidden);
 int dkd_block_bwd_workspace_carve(void* ws, int32_t B, int32_t N, int32_t D, int32_t hidden, DkdBlockGrads* gr);
 
+/* ---------------------------------------------------------------- small glue of the step (one launch each instead of ATen chains) */
+/* x bf16 [n] *= *scalar_dev (f32 product).  The upstream gradient of a loss term is a 0-dim DEVICE tensor in autograd's backward
+ * (torch: grad_output * local gradient, model/loss.py:326-329 under loss.backward()); n % 8 == 0. */
+int dkd_scale_bf16(void* x, const float* scalar_dev, int64_t n, void* stream);
+/* dst bf16 [rows, Cp] = bf16(src f32 [rows, C] * (*scalar_dev, or 1 when null)), columns C .. Cp zero: the K-padded operand of the
+ * classifier head's dgrad / wgrad GEMMs (timm VisionTransformer.head, nn.Linear backward). */
+int dkd_cast_pad_bf16(const float* src, int32_t ld_src, const float* scalar_dev, void* dst, int32_t rows, int32_t C, int32_t Cp, void* stream);
+/* DropPath keep masks of a whole step: out f32 [n, B] = (u < keep_prob[i]) / keep_prob[i], u from a counter-based generator seeded
+ * by `seed` (timm.layers.DropPath: x.new_empty(shape).bernoulli_(keep_prob) / keep_prob, one draw per sample and branch). */
+int dkd_droppath_scales(float* out, const float* keep_prob, int32_t n, int32_t B, uint64_t seed, void* stream);
+
 /* ---------------------------------------------------------------- LRKD target: truncated SVD without factorising T (model/loss.py:318-324) */
 /* Batched cyclic Jacobi: A f32 [batch, n, n] symmetric, n <= 128 -> evals [batch, n] (unsorted), evecs [batch, n, n]
  * (column j pairs with evals[j]).  One workgroup per matrix, LDS-resident; at most `sweeps` sweeps, stops after the first sweep that

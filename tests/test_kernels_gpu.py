@@ -673,6 +673,68 @@ def test_lowrank_chain(ops, Dt):
     close((V[:, :, :32] * V1[:, :, :32]).sum(1), torch.ones(L, 32, device=dev()), 1e-3, "warm restart keeps vectors and signs")
 
 
+def test_step_glue_kernels(ops):
+    """The three launches that replaced ATen chains on the step: bf16 x device-scalar in f32, the K-padded
+    bf16 cast of the head's logit gradient, the DropPath masks of a whole step from one counter-based draw."""
+    x = rnd(1000, 64, seed=3).to(BF16)
+    g = torch.tensor(0.3712, device=dev())
+    ref = (x.float() * g).to(BF16)
+    got = ops.scale_bf16_(x.clone(), g.reshape(1))
+    assert torch.equal(got, ref)
+    src = rnd(37, 1000, seed=4)
+    pad = ops.cast_pad_bf16(src, 1024)
+    assert pad.shape == (37, 1024) and torch.equal(pad[:, :1000], src.to(BF16)) and int(pad[:, 1000:].abs().max()) == 0
+    view = rnd(37, 1200, seed=5)[:, 100:1100]                       # a strided source (row stride 1200)
+    pad = ops.cast_pad_bf16(view, 1024, scalar=g.reshape(1))
+    assert torch.equal(pad[:, :1000], (view * g).to(BF16))
+    keep = torch.tensor([1.0, 0.95, 0.9, 0.5], device=dev())
+    B = 20000
+    a = ops.droppath_scales(keep, B, 1234)
+    b = ops.droppath_scales(keep, B, 1234)
+    c = ops.droppath_scales(keep, B, 1235)
+    assert torch.equal(a, b) and not torch.equal(a, c)
+    for i, k in enumerate(keep.tolist()):
+        vals = torch.unique(a[i]).tolist()
+        assert all(abs(v) < 1e-12 or abs(v - 1.0 / k) < 1e-6 for v in vals), vals
+        rate = (a[i] > 0).float().mean().item()
+        assert abs(rate - k) < 4 * (k * (1 - k) / B) ** 0.5 + 1e-9, (k, rate)        # 4 sigma of a Bernoulli mean
+        assert abs(a[i].mean().item() - 1.0) < 5 * ((1 - k) / (k * B)) ** 0.5 + 1e-9  # E[mask / keep] = 1
+    # draws of different branches / samples are not correlated: the two halves of one row, and two rows, agree at chance level
+    m = (a[3] > 0).float()
+    assert abs((m[:B // 2] * m[B // 2:]).mean().item() - 0.25) < 0.02
+    assert abs(((a[2] > 0).float() * m).mean().item() - 0.45) < 0.02
+
+
+def test_patch_matrix_is_shared_between_teacher_and_student(ops, monkeypatch):
+    """deltakd_amd.vit._shared_patches: the bf16 patch matrix of a batch is gathered once and used by both models (also across streams);
+    a rewritten batch (same storage, new version) and another patch size gather again."""
+    from deltakd_amd import vit
+    torch.manual_seed(1)
+    t = vit.VisionTransformer(128, 2, 2, 10, True, 0.0, img_size=32, patch_size=8).to(dev()).eval()
+    s = vit.VisionTransformer(64, 2, 1, 10, False, 0.0, img_size=32, patch_size=8).to(dev()).eval()
+    x = rnd(4, 3, 32, 32, seed=2)
+    calls = []
+    real = ops.im2col_patches
+    monkeypatch.setattr(vit.ops, "im2col_patches", lambda img, p: (calls.append(1), real(img, p))[1])
+    side = torch.cuda.Stream()
+    with torch.no_grad():
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            a1 = t(x)                                   # the teacher gathers, on its own stream
+        b1 = s(x)                                       # the student finds the matrix (and waits for that stream's event)
+        torch.cuda.synchronize()
+        assert len(calls) == 1
+        monkeypatch.setenv("DKD_NO_SHARED_PATCHES", "1")
+        a2, b2 = t(x), s(x)
+        assert len(calls) == 3 and torch.equal(a1, a2) and torch.equal(b1, b2)
+        monkeypatch.delenv("DKD_NO_SHARED_PATCHES")
+        x.mul_(2.0)                                     # same tensor object, rewritten in place: the cached matrix is stale
+        b3 = s(x)
+        assert len(calls) == 4
+        monkeypatch.setenv("DKD_NO_SHARED_PATCHES", "1")
+        assert torch.equal(b3, s(x.clone()))
+
+
 def test_lowrank_targets_vs_svd(ops):
     """Dt = 768 (subspace iteration + Rayleigh-Ritz path): U_k S_k against torch.linalg.svd on the host, up to column sign.
     Cold start, then a warm-started call on a different batch drawn from the same feature distribution."""

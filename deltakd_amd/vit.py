@@ -416,16 +416,17 @@ def wgrad_group_size(model):
 # the samples the student saw): the bf16 patch matrix [B * 196, 768] is gathered once per batch and shared -- the second model to ask
 # (the student, a batch of lookahead later) waits on the event of the stream that produced it.  Keyed by the tensor OBJECT and its
 # version counter, held weakly: a new batch, or the same storage rewritten in place, gathers again.  DKD_NO_SHARED_PATCHES=1 disables.
-_PATCH_CACHE = weakref.WeakKeyDictionary()
+_PATCH_CACHE = {}            # id(tensor) -> (weakref to the tensor, key, patches, event, stream); dropped when the tensor dies
 
 
 def _shared_patches(img, p):
     if os.environ.get("DKD_NO_SHARED_PATCHES"):
         return ops.im2col_patches(img, p)
     cur = torch.cuda.current_stream(img.device)
-    hit = _PATCH_CACHE.get(img)
-    if hit is not None and hit[0] == (img._version, p, img.data_ptr()):
-        _, patches, ev, st = hit
+    key = (img._version, p, img.data_ptr(), tuple(img.shape))
+    hit = _PATCH_CACHE.get(id(img))
+    if hit is not None and hit[0]() is img and hit[1] == key:
+        _, _, patches, ev, st = hit
         if st != cur.cuda_stream:
             cur.wait_event(ev)
             patches.record_stream(cur)
@@ -433,7 +434,9 @@ def _shared_patches(img, p):
     patches = ops.im2col_patches(img, p)
     ev = torch.cuda.Event()
     ev.record(cur)
-    _PATCH_CACHE[img] = ((img._version, p, img.data_ptr()), patches, ev, cur.cuda_stream)
+    if hit is None:
+        weakref.finalize(img, _PATCH_CACHE.pop, id(img), None)
+    _PATCH_CACHE[id(img)] = (weakref.ref(img), key, patches, ev, cur.cuda_stream)
     return patches
 
 

@@ -483,7 +483,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const DkdGemm g, const 
 // and nothing else), 0 otherwise.  Known, the waits that follow an epilogue count its stores as outstanding instead of draining
 // them: they retire under the next tile's first phases.
 // ABL: dev-only ablation bits (build with -DDKD_NT256_ABL=n; results are then wrong, timings are the point): 1 no epilogue,
-// 2 two units per tile, 4 no LDS-DMA in the loop, 8 no barriers, 16 no fragment reads, 32 no MFMAs, 64 LDS-DMA pieces of full 128-byte lines.
+// 2 two units per tile, 4 no LDS-DMA in the loop, 8 no barriers, 16 no fragment reads, 32 no MFMAs, 64 LDS-DMA pieces of full 128-byte lines,
+// 128 every second workgroup of an XCD skips its bf16 stores.
 // WN: waves along N.  4: the 256 x 256 tile, 8 waves, ring of 5 units, one workgroup per CU (qkv / fc1 of the teacher).
 //     2: a 256 x 128 tile, 4 waves, ring of 3 units (72 KiB), two workgroups per CU -- for N = 768 (proj / fc2), where 256-wide
 //        tiles leave 256 CUs with 2.3 rounds of work; it moves 25 % less operand data through the LDS-DMA path than the
@@ -702,7 +703,7 @@ __global__ __launch_bounds__(128 * WN, WN == 4 ? 1 : 2) void gemm_nt256_kernel(c
     // ---- epilogue, straight from registers: lane holds C[m0 + wr*128 + i*16 + frow][n0 + wc*64 + 32*jp + 8*fg .. +7]
     const int L = tile_of(k);
     const int m0 = (L / tiles_n) * 256, n0 = (L % tiles_n) * BN;
-    exact = m0 + 256 <= g.M;              // no row of the tile is masked off: every wave issues all its stores
+    exact = m0 + 256 <= g.M && !((ABL & 128) && (slot_in_xcd & 1));      // no row of the tile is masked off: every wave issues all its stores
     if (ABL & 1) {
       float t = 0.f;
       for (int i = 0; i < 8; ++i)
@@ -832,8 +833,11 @@ __global__ __launch_bounds__(128 * WN, WN == 4 ? 1 : 2) void gemm_nt256_kernel(c
           const uint4 d0 = odd ? recv : pk[0], d1 = odd ? pk[1] : recv;      // line of the even row, line of the odd row
           const int me = m - (odd ? 1 : 0);
           bf16_t* cp = (bf16_t*)g.C + (size_t)me * g.ldc + nb + (odd ? 32 : 0);
-          if (me < g.M) __builtin_nontemporal_store(u32x4{d0.x, d0.y, d0.z, d0.w}, (u32x4*)cp);
-          if (me + 1 < g.M) __builtin_nontemporal_store(u32x4{d1.x, d1.y, d1.z, d1.w}, (u32x4*)(cp + g.ldc));
+          // (ablation bit 128: every second workgroup of an XCD keeps its results -- are the epilogue's stores bound per CU or by the
+          // chip's HBM write rate?  timings only)
+          const bool keep_out = !((ABL & 128) && (slot_in_xcd & 1));
+          if (me < g.M && keep_out) __builtin_nontemporal_store(u32x4{d0.x, d0.y, d0.z, d0.w}, (u32x4*)cp);
+          if (me + 1 < g.M && keep_out) __builtin_nontemporal_store(u32x4{d1.x, d1.y, d1.z, d1.w}, (u32x4*)(cp + g.ldc));
         } else if (m < g.M) {
           EpiIn in[2];
 #pragma unroll

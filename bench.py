@@ -53,6 +53,29 @@ def make_args(cfg, batch, epochs=1):
     return SimpleNamespace(**a)
 
 
+# The student's fused kernels (the path the north star's 40 % MFMA target names) and their ALGORITHMIC bytes per launch at the headline
+# shape (B = 256, N = 197, D = 192, hidden 768; every tensor the launch must touch, once -- DESIGN.md section 4):
+STUDENT_KERNELS = ("mlp192_kernel<0", "mlp192_kernel<1", "attn192_fwd_kernel", "attn192_bwd_kernel", "gemm_nt_lnbwd_kernel", "gemm_tn192g_kernel")
+
+
+def student_algorithmic_bytes(B, N=197, D=192, hidden=768, blocks_per_wgrad_launch=6):
+    M = B * N
+    return {
+        # x1 f32 in, y2 bf16, pre + h bf16 [M, hidden], x2 f32 out, next block's y1 bf16 (+ weights, negligible)
+        "mlp192_kernel<0>": M * (4 * D + 2 * D + 2 * 2 * hidden + 4 * D + 2 * D),
+        # g f32 in / out, pre bf16 in, dH bf16 out, x1 f32 in, dF bf16 in, dF2 bf16 out
+        "mlp192_kernel<1>": M * (2 * 4 * D + 2 * 2 * hidden + 4 * D + 2 * 2 * D),
+        # y1 bf16 in, qkv bf16 out (the backward reads it), o bf16 out, x f32 in / out
+        "attn192_fwd_kernel": M * (2 * D + 2 * 3 * D + 2 * D + 2 * 4 * D),
+        # dY bf16, qkv bf16, o bf16 in; dqkv bf16 out
+        "attn192_bwd_kernel": M * (2 * D + 2 * 3 * D + 2 * D + 2 * 3 * D),
+        # dqkv bf16 in (K = 3 D), x f32 in, g f32 in / out, next scale-cast bf16 out
+        "gemm_nt_lnbwd_kernel": M * (2 * 3 * D + 4 * D + 2 * 4 * D + 2 * D),
+        # four weight gradients per block: both operands of each, once (fc1: dH | y2, fc2: dF | h, qkv: dqkv | y1, proj: dY | o)
+        "gemm_tn192g_kernel": blocks_per_wgrad_launch * M * 2 * ((hidden + D) * 2 + (3 * D + D) + (D + D)),
+    }
+
+
 def _host_cpus():
     """(usable cpus, model string): the scheduler affinity, cut down by a cgroup CPU quota when there is one."""
     try:
@@ -143,7 +166,7 @@ def measure_traffic_live(config, batch, timeout_s=240):
     exe = shutil.which("rocprofv3")
     if exe is None:
         return None, "rocprofv3 not on PATH"
-    fams = ("gemm_nt_kernel<64", "gemm_nt_kernel<128", "gemm_nt256_kernel")
+    fams = ("gemm_nt_kernel<64", "gemm_nt_kernel<128", "gemm_nt256_kernel") + STUDENT_KERNELS
     raw = collections.defaultdict(dict)
     tmp = tempfile.mkdtemp(prefix="dkd_pmc_", dir="/tmp")
     env = dict(os.environ, TMPDIR="/tmp", DKD_BENCH_PMC_CHILD="1")
@@ -183,7 +206,7 @@ def measure_traffic_live(config, batch, timeout_s=240):
         return None, f"live PMC passes failed: {e}"
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
-    res = {(k + ">" if k.endswith(("<64", "<128")) else k): (2 * v.get("FETCH_SIZE", 0.0) + v.get("WRITE_SIZE", 0.0)) * 1024
+    res = {(k + ">" if k.endswith(("<64", "<128", "<0", "<1")) else k): (2 * v.get("FETCH_SIZE", 0.0) + v.get("WRITE_SIZE", 0.0)) * 1024
            for k, v in raw.items() if "FETCH_SIZE" in v and "WRITE_SIZE" in v}
     if not res:
         return None, "the PMC passes produced no rows for the NT-GEMM kernels"
@@ -386,6 +409,17 @@ def main():
             "student_block_fwd": {"ms": sf[2], "tflops": sf[0] / (sf[2] * 1e-3) / 1e12 if sf[2] else 0.0,
                                   "gbps": sf[1] / (sf[2] * 1e-3) / 1e9 if sf[2] else 0.0},
         }
+    if roofline_student is not None:
+        alg = student_algorithmic_bytes(a.batch)
+        if live_traffic:
+            roofline_student["traffic"] = {k: {"measured_bytes_per_launch": live_traffic.get(k), "algorithmic_bytes_per_launch": alg[k],
+                                               "ratio": (live_traffic[k] / alg[k]) if live_traffic.get(k) else None}
+                                           for k in alg}
+            roofline_student["traffic_how"] = ("the same two rocprofv3 --pmc passes as roofline.traffic (FETCH_SIZE / WRITE_SIZE, gfx950 correction); "
+                                               "gemm_nt_lnbwd_kernel is the qkv dgrad + norm1 backward (K = 576; the fc1 dgrad lives in mlp192_kernel<1>); "
+                                               "gemm_tn192g_kernel is one launch per 6 blocks")
+        else:
+            roofline_student["traffic"] = None
     achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
     # HBM-side bytes per launch of the dominant kernel: NOT measured in this run (PMC counters need rocprofv3); read from the committed
     # summary of the separate `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes of this same command (tools_dev/collect_profiles.sh)

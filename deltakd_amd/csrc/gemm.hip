@@ -836,8 +836,13 @@ __global__ __launch_bounds__(128 * WN, WN == 4 ? 1 : 2) void gemm_nt256_kernel(c
           // (ablation bit 128: every second workgroup of an XCD keeps its results -- are the epilogue's stores bound per CU or by the
           // chip's HBM write rate?  timings only)
           const bool keep_out = !((ABL & 128) && (slot_in_xcd & 1));
-          if (me < g.M && keep_out) __builtin_nontemporal_store(u32x4{d0.x, d0.y, d0.z, d0.w}, (u32x4*)cp);
-          if (me + 1 < g.M && keep_out) __builtin_nontemporal_store(u32x4{d1.x, d1.y, d1.z, d1.w}, (u32x4*)(cp + g.ldc));
+          if (ABL & 256) {                 // (ablation bit 256: ordinary stores -- does the consumer find the tensor in the Infinity Cache?)
+            if (me < g.M) *(u32x4*)cp = u32x4{d0.x, d0.y, d0.z, d0.w};
+            if (me + 1 < g.M) *(u32x4*)(cp + g.ldc) = u32x4{d1.x, d1.y, d1.z, d1.w};
+          } else {
+            if (me < g.M && keep_out) __builtin_nontemporal_store(u32x4{d0.x, d0.y, d0.z, d0.w}, (u32x4*)cp);
+            if (me + 1 < g.M && keep_out) __builtin_nontemporal_store(u32x4{d1.x, d1.y, d1.z, d1.w}, (u32x4*)(cp + g.ldc));
+          }
         } else if (m < g.M) {
           EpiIn in[2];
 #pragma unroll
@@ -1471,7 +1476,7 @@ template <int WR, int PB>
 __device__ __forceinline__ void tn192d_body(char* smem, const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, float* C, int M,
                                             int N1, int N2, int lda, int ldb, int ldc, const DkdRowMap& amap, const DkdRowMap& bmap,
                                             int units_per_split, float* __restrict__ colsum, int tiles1, const bool SWAP, int bid,
-                                            int nblk, int rot = 0) {
+                                            int nblk, int rot = 0, int tile_in = -1, int split_in = 0) {
   using Cfg = TndCfg<WR>;
   constexpr int A_ST = Cfg::A_ST, UNIT = Cfg::UNIT, RING = Cfg::RING, PIECES = 2 + PB, A_ROWB = Cfg::A_ROWB, AW = Cfg::AW;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -1483,8 +1488,9 @@ __device__ __forceinline__ void tn192d_body(char* smem, const bf16_t* __restrict
   // (rot: a group launch pads every problem's block range to a multiple of 8 and the padding sits at the END of the remapped list, i.e.
   // on the last XCDs; rotating the XCD labels by the problem's index spreads the idle slots over all eight -- with one 8-wave workgroup
   // per CU and 12 real blocks of 16, two XCDs had no work at all and the others ran two rounds)
-  const int L = xcd_remap((bid & ~7) | ((bid + rot) & 7), nblk);
-  const int tile = L % tiles1, split = L / tiles1;
+  // (tile_in >= 0: the caller placed this block -- the group launch's one-XCD-per-split table, gemm_tn192g_kernel)
+  const int L = tile_in >= 0 ? 0 : xcd_remap((bid & ~7) | ((bid + rot) & 7), nblk);
+  const int tile = tile_in >= 0 ? tile_in : L % tiles1, split = tile_in >= 0 ? split_in : L / tiles1;
   const int n1_0 = tile * AW;
   const int U_all = (M + 31) / 32;
   const int u_begin = split * units_per_split;
@@ -1692,10 +1698,31 @@ constexpr int TN_GROUP_MAX = 24;        // 24 x 96 B of kernel arguments (the li
 struct TnGroup {
   TnProb p[TN_GROUP_MAX];
   int n;
+  // xsplits > 0: XCD x = blockIdx % 8 works on M split x % xsplits of the problems gstart[x / xsplits] .. gstart[x / xsplits + 1], one tile
+  // per block in slot order: ALL tiles of a (problem, split) run on one XCD, so the rows of its 192-wide operand come from memory once.
+  // (Round 3's per-problem remap spread a split's 6 tiles over two XCDs, 5 over two or three: the PMC counters of round 4 showed
+  // 2.60 GB per six-block launch against 1.86 GB algorithmic -- those operands fetched about twice.)
+  int xsplits, gstart[9];
 };
 template <int WR>
 __global__ __launch_bounds__(128 * WR, WR == 2 ? 2 : 1) void gemm_tn192g_kernel(const TnGroup grp) {
   __shared__ __attribute__((aligned(16))) char smem[TndCfg<WR>::SMEM];
+  if constexpr (WR == 2) {
+    if (grp.xsplits > 0) {
+      const int x = blockIdx.x & 7, gi = x / grp.xsplits;
+      int k = grp.gstart[gi], rem = blockIdx.x >> 3;
+      const int kend = grp.gstart[gi + 1];
+      while (k < kend && rem >= grp.p[k].tiles1) {
+        rem -= grp.p[k].tiles1;
+        ++k;
+      }
+      if (k >= kend) return;
+      const TnProb& q = grp.p[k];
+      tn192d_body<2, 3>(smem, q.A, q.B, q.C, q.M, q.N1, q.N2, q.lda, q.ldb, q.ldc, q.amap, q.bmap, q.units_per_split, q.colsum, q.tiles1,
+                        q.swap != 0, 0, 0, 0, rem, x % grp.xsplits);
+      return;
+    }
+  }
   int bid = blockIdx.x, k = 0;
   while (k + 1 < grp.n && bid >= grp.p[k].n_blocks) {
     bid -= grp.p[k].n_blocks;
@@ -1999,6 +2026,40 @@ int tn_group_launch(const DkdTnProblem* probs, int n, void* stream) {
     } else {                            // shapes the ring kernel does not take: launched on their own
       int rc = dkd_gemm_tn(q.A, q.B, q.C, q.M, q.N1, q.N2, q.lda, q.ldb, q.ldc, q.amap, q.bmap, q.a_colsum, stream);
       if (rc != DKD_OK) return rc;
+    }
+  }
+  grp.xsplits = 0;
+  static const int xsplit_env = getenv("DKD_TN_GROUP_XSPLIT") ? atoi(getenv("DKD_TN_GROUP_XSPLIT")) : 1;      // (0: round 3's mapping, A/B)
+  if (grp.n > 0 && !wide && xsplit_env && blocks_env == 0 && (splits == 1 || splits == 2 || splits == 4 || splits == 8)) {
+    // one XCD per (problem, M split): possible when every problem really got `splits` splits and the problems divide into 8 / splits
+    // groups of about equal tile count
+    const int G = 8 / splits;
+    bool ok = grp.n >= G;
+    int tiles_all = 0;
+    for (int i = 0; i < grp.n && ok; ++i) {
+      const TnProb& q = grp.p[i];
+      ok = cdiv(cdiv(q.M, 32), q.units_per_split) == splits;
+      tiles_all += q.tiles1;
+    }
+    if (ok) {
+      int k = 0, acc = 0, worst = 0;
+      for (int gi = 0; gi < G; ++gi) {
+        grp.gstart[gi] = k;
+        const int want = (int)((long)tiles_all * (gi + 1) / G);
+        int mine = 0;
+        while (k < grp.n && (gi == G - 1 || acc + grp.p[k].tiles1 / 2 < want || mine == 0) && grp.n - k > G - 1 - gi) {
+          acc += grp.p[k].tiles1;
+          mine += grp.p[k].tiles1;
+          ++k;
+        }
+        worst = mine > worst ? mine : worst;
+      }
+      grp.gstart[G] = grp.n;
+      for (int gi = G + 1; gi < 9; ++gi) grp.gstart[gi] = grp.n;
+      if (k == grp.n && worst * 8 <= (slots_env > 0 ? slots_env : 512) + 64) {
+        grp.xsplits = splits;
+        total = worst * 8;
+      }
     }
   }
   if (grp.n > 0) {

@@ -514,6 +514,36 @@ def _gram_of(taps, npre):
     return torch.stack(out)
 
 
+@pytest.mark.parametrize("blocks", [3, 6])
+def test_grouped_weight_gradients_one_xcd_per_split(ops, blocks):
+    """dkd_gemm_tn_group at the student's backward shapes, 3 and 6 blocks per launch: 57 / 114 tiles = 8 / 4 M splits, the launches that
+    take the one-XCD-per-(problem, split) placement of round 5 (csrc/gemm.hip: TnGroup.xsplits; every block of the launch gets its
+    (problem, tile, split) from the XCD table, nothing from the per-problem remap).  Every gradient and every bias gradient of the launch
+    against fp32 matmul of the same bf16 operands -- a tile or a split that the table skipped or handed out twice shows as a wrong
+    block of some output."""
+    M, D, Hd = B * NS_, 192, 768
+    g = torch.Generator(device=DEV).manual_seed(50 + blocks)
+    probs, refs = [], []
+    for b in range(blocks):
+        for n1, n2 in ((D, Hd), (Hd, D), (D, D), (3 * D, D)):
+            a = (torch.randn(M, n1, device=DEV, generator=g) * 0.1).to(BF16)
+            bb = (torch.randn(M, n2, device=DEV, generator=g) * 0.1).to(BF16)
+            out = torch.zeros(n1, n2, device=DEV)
+            cs = torch.zeros(n1, device=DEV)
+            probs.append(dict(a=a, b=bb, out=out, colsum=cs))
+    ops.gemm_tn_group(probs)
+    torch.cuda.synchronize()
+    for i, q in enumerate(probs):
+        ref = q["a"].float().t() @ q["b"].float()
+        err = ((q["out"] - ref).norm() / ref.norm()).item()
+        assert err < 2e-3, (i, err)
+        # no tile missing or doubled: the worst 128 x 192 block of the output is as good as the whole
+        blk = (q["out"] - ref).abs().amax().item() / ref.abs().amax().item()
+        assert blk < 1e-2, (i, blk)
+        rs = q["a"].float().sum(0)
+        assert ((q["colsum"] - rs).norm() / rs.norm()).item() < 2e-3, i
+
+
 @pytest.mark.parametrize("epi", ["bias", "gelu"])
 def test_wide_gemm_ragged_rows(ops, epi):
     """The persistent 256 x 256 kernel on an M that is odd and not a multiple of 256 (edge tiles: clamped A rows, masked stores, the

@@ -9,13 +9,15 @@ import collections, csv, glob, json, os, re, subprocess, sys
 
 root, config, out = sys.argv[1], sys.argv[2], sys.argv[3]
 KEYS = ("gemm_nt_kernel<64", "gemm_nt_kernel<128", "gemm_nt256_kernel", "gemm_tn_kernel", "gemm_tn192g_kernel", "gemm_tn192d_kernel", "gemm_tn192_kernel", "attn_fwd_ring_kernel",
-        "attn_fwd_kernel", "attn_bwd_dq_kernel", "attn_bwd_dkv_kernel", "ln_fwd_kernel", "ln_bwd_kernel")
+        "attn_fwd_kernel", "attn_bwd_dq_kernel", "attn_bwd_dkv_kernel", "ln_fwd_kernel", "ln_bwd_kernel",
+        # the student's fused kernels (round 5: VERDICT round 4, item 4a)
+        "mlp192_kernel<0", "mlp192_kernel<1", "attn192_fwd_kernel", "attn192_bwd_kernel", "gemm_nt_lnbwd_kernel", "gemm_tn_kernel")
 
 
 def sym(name):
     for k in KEYS:
         if k in name:
-            return k + ">" if k.endswith(("<64", "<128")) else k        # any epilogue instantiation of the tile kernel
+            return k + ">" if k.endswith(("<64", "<128", "<0", "<1")) else k        # any epilogue instantiation of the tile kernel
     return None
 
 

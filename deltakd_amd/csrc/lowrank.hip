@@ -491,65 +491,77 @@ __global__ __launch_bounds__(256) void lr_mult_kernel(const float* __restrict__ 
       }
     }
   }
-  // The right operand travels through a ring of FOUR register sets: chunk c + 4 is requested when chunk c is multiplied and written to
-  // LDS three iterations later (one chunk of FMAs is ~0.5 us, a load from L2 / HBM 1-2 us: with one chunk of lookahead the loop ran at
-  // the load latency, 56 us per launch).
-  const int f0 = tid, f1 = tid + 256, f2 = tid + 512;
-  const int fo0 = (f0 / 24) * LB + 4 * (f0 % 24), fo1 = (f1 / 24) * LB + 4 * (f1 % 24), fo2 = (f2 / 24) * LB + 4 * (f2 % 24);
-  f32x4 nb[4][3];
-  const int nchunk = Dt >> 5;
-#define LR_FETCH(slot_, c_)                                                   \
-  if ((c_) < nchunk) {                                                        \
-    const float* src_ = Bsrc + (size_t)(c_) * 32 * LB;                        \
-    nb[slot_][0] = *(const f32x4*)&src_[fo0];                                 \
-    nb[slot_][1] = *(const f32x4*)&src_[fo1];                                 \
-    nb[slot_][2] = *(const f32x4*)&src_[fo2];                                 \
-  }
-#define LR_STASH(slot_, c_)                                                   \
-  if ((c_) < nchunk) {                                                        \
-    float* dst_ = Bs + ((c_) & 1) * 32 * LB;                                  \
-    *(f32x4*)&dst_[fo0] = nb[slot_][0];                                       \
-    *(f32x4*)&dst_[fo1] = nb[slot_][1];                                       \
-    *(f32x4*)&dst_[fo2] = nb[slot_][2];                                       \
+  // ---- K loop on the fp32 matrix cores.  Round 5's first form (one thread = 2 x 3 outputs, both operands through LDS) spent 30 us
+  // here: 5 LDS reads per 6 multiply-adds at one wave per SIMD.  Now wave w multiplies the K range [w Dt / 4, (w + 1) Dt / 4) for the
+  // whole 16 x 96 tile with v_mfma_f32_16x16x4_f32 (A = 16 rows x 4 k of the G panel, from LDS; B = 4 k x 16 columns of the right
+  // operand, read from global memory straight into registers -- every wave needs different rows of it, so there is nothing to share
+  // through LDS); the four partial tiles are added through LDS afterwards.  One 16-byte + one 8-byte load per lane and k row feed six
+  // column tiles: tile t < 4 is the columns {4 c + t}, tiles 4, 5 the columns {64 + 2 c + (t - 4)}, c = lane % 16 (a permutation of the
+  // columns, undone when the partial tiles are written).  A lane's four k rows of a group of 16 are k0 + 4 q + e (q = lane / 16), e = the
+  // MFMA step: any four distinct rows per step will do as long as A and B agree.  Four groups (1 KiB per lane) are in flight.
+  const int lane = tid & 63, wv = tid >> 6, q4 = lane >> 4, c16 = lane & 15;
+  const int kw0 = wv * (Dt >> 2), ngrp = Dt >> 6;          // groups of 16 k per wave (Dt % 64 == 0: host-checked)
+  f32x4 b4[4][4];
+  dkd_f32x2 b2[4][4];
+  const float* bsrc = Bsrc + (size_t)(kw0 + 4 * q4) * LB;
+#define LR_FETCH(slot_, g_)                                                                         \
+  if ((g_) < ngrp) {                                                                                \
+    _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                 \
+      const float* r_ = bsrc + (size_t)((g_) * 16 + e) * LB;                                        \
+      b4[slot_][e] = *(const f32x4*)&r_[4 * c16];                                                   \
+      b2[slot_][e] = *(const dkd_f32x2*)&r_[64 + 2 * c16];                                          \
+    }                                                                                               \
   }
   LR_FETCH(0, 0)
   LR_FETCH(1, 1)
   LR_FETCH(2, 2)
   LR_FETCH(3, 3)
-  LR_STASH(0, 0)
-  __syncthreads();
+  __syncthreads();                                           // the panel (and C) are in LDS
   LR_STAMP(0, 1);
-  float acc[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
-  const float* a0p = As + (2 * ty) * lda;
-  const float* a1p = a0p + lda;
-#define LR_STEP(slot_, c_)                                                    \
-  if ((c_) < nchunk) {                                                        \
-    LR_FETCH(slot_, (c_) + 4)                                                 \
-    const float* bp = Bs + ((c_) & 1) * 32 * LB + tx;                         \
-    const int k0 = (c_) << 5;                                                 \
-    _Pragma("unroll") for (int kk = 0; kk < 32; kk += 4) {                    \
-      const f32x4 a0 = *(const f32x4*)&a0p[k0 + kk], a1 = *(const f32x4*)&a1p[k0 + kk]; \
-      _Pragma("unroll") for (int u = 0; u < 4; ++u) {                         \
-        _Pragma("unroll") for (int j = 0; j < 3; ++j) {                       \
-          const float b = bp[(kk + u) * LB + 32 * j];                         \
-          acc[0][j] = fmaf(a0[u], b, acc[0][j]);                              \
-          acc[1][j] = fmaf(a1[u], b, acc[1][j]);                              \
-        }                                                                     \
-      }                                                                       \
-    }                                                                         \
-    LR_STASH(((slot_) + 1) & 3, (c_) + 1)                                     \
-    __syncthreads();                                                          \
+  f32x4 macc[6];
+#pragma unroll
+  for (int t = 0; t < 6; ++t) macc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const float* arow = As + c16 * lda + kw0 + 4 * q4;
+#define LR_STEP(slot_, g_)                                                                          \
+  if ((g_) < ngrp) {                                                                                \
+    const f32x4 a4 = *(const f32x4*)&arow[(g_) * 16];                                               \
+    _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                 \
+      _Pragma("unroll") for (int t = 0; t < 4; ++t)                                                 \
+        macc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[e], b4[slot_][e][t], macc[t], 0, 0, 0);  \
+      macc[4] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[e], b2[slot_][e][0], macc[4], 0, 0, 0);     \
+      macc[5] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[e], b2[slot_][e][1], macc[5], 0, 0, 0);     \
+    }                                                                                               \
+    LR_FETCH(slot_, (g_) + 4)                                                                       \
   }
-  for (int c = 0; c < nchunk; c += 4) {
-    LR_STEP(0, c)
-    LR_STEP(1, c + 1)
-    LR_STEP(2, c + 2)
-    LR_STEP(3, c + 3)
+  for (int g = 0; g < ngrp; g += 4) {
+    LR_STEP(0, g)
+    LR_STEP(1, g + 1)
+    LR_STEP(2, g + 2)
+    LR_STEP(3, g + 3)
   }
 #undef LR_STEP
-  LR_STAMP(0, 2);
 #undef LR_FETCH
-#undef LR_STASH
+  // the four waves' partial tiles -> LDS (column permutation undone), summed into the (ty, tx) layout the epilogue works in
+  {
+    float* red = Bs + wv * LR_ROWS * LB;
+#pragma unroll
+    for (int t = 0; t < 6; ++t) {
+      const int col = t < 4 ? 4 * c16 + t : 64 + 2 * c16 + (t - 4);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) red[(4 * q4 + i) * LB + col] = macc[t][i];
+    }
+  }
+  __syncthreads();
+  float acc[2][3];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int o = (2 * ty + i) * LB + tx + 32 * j;
+      acc[i][j] = (Bs[o] + Bs[LR_ROWS * LB + o]) + (Bs[2 * LR_ROWS * LB + o] + Bs[3 * LR_ROWS * LB + o]);
+    }
+  __syncthreads();                                           // (the tiles below reuse this LDS)
+  LR_STAMP(0, 2);
   // ---- epilogue: the tile through the transform, out, and into the 96 x 96 Gram matrices
   float* Zt = Bs;                  // [16][96]
   float* Yt = Bs + LR_ROWS * LB;
@@ -638,64 +650,145 @@ __global__ __launch_bounds__(256) void lr_mult_kernel(const float* __restrict__ 
   LR_STAMP(0, 5);
 }
 
-// ---- Cholesky and triangular inverse for the chain's stages (1024 threads, row stride LDJ).  The first forms above spend their time in
-// integer divisions (every work item decodes (i, j) from a flat index by a run-time extent: ~100 us for 96 columns) and in a
-// one-thread-per-column substitution whose every step is an LDS round trip (~55 us).
-// Cholesky: right-looking, one barrier per column; the trailing update is a fixed 32 x 32 thread grid over 3 x 3 elements each.
-__device__ void cholesky96(float* A, float floor_) {
+// ---- Cholesky and triangular inverse for the chain's stages (1024 threads = a 32 x 32 grid of 3 x 3 blocks, row stride LDJ).
+// The first forms above spend their time in integer divisions (every work item decodes (i, j) from a flat index by a run-time
+// extent: ~100 us for 96 columns) and in a one-thread-per-column substitution whose every step is an LDS round trip (~55 us); a
+// fixed 32 x 32 thread grid with one barrier per column still took 48 us -- 96 rounds of read-modify-write passes over the trailing
+// matrix in LDS, issue-bound (s_memrealtime stamps, tools_dev/lowrank_stamps.py).
+// Cholesky, third form: the trailing matrix lives in REGISTERS -- thread (ty, tx), ty >= tx, owns the 3 x 3 block of rows 3 ty.. and
+// columns 3 tx.. for the whole factorisation; a step eliminates one block column: its owners publish their current blocks in a
+// two-deep LDS panel buffer (one barrier per step, 32 steps), every thread below / right of the pivot factors the 3 x 3 pivot block
+// itself (10 flops), substitutes its three panel rows and its three panel columns through it and subtracts their product from its
+// block.  Pivots that fp32 cancellation drove below `floor_` are clamped.  Pb: scratch of 2 x 96 x 4 floats.  On return A holds L
+// (upper triangle zero).
+__device__ void cholesky96(float* A, float* Pb, float floor_) {
   const int tid = threadIdx.x, tx = tid & 31, ty = tid >> 5;
-  for (int k = 0; k < LB; ++k) {
-    __syncthreads();
-    const float inv = 1.f / fmaxf(A[k * LDJ + k], floor_);
+  const bool lower = ty >= tx;
+  float a[3][3];
 #pragma unroll
-    for (int a = 0; a < 3; ++a) {
-      const int i = ty + 32 * a;
-      if (i <= k) continue;
-      const float lik = A[i * LDJ + k] * inv;
+  for (int r = 0; r < 3; ++r)
 #pragma unroll
-      for (int b = 0; b < 3; ++b) {
-        const int j = tx + 32 * b;
-        if (j > k && j <= i) A[i * LDJ + j] -= lik * A[j * LDJ + k];
-      }
+    for (int c = 0; c < 3; ++c) a[r][c] = (lower && (ty > tx || c <= r)) ? A[(3 * ty + r) * LDJ + 3 * tx + c] : 0.f;
+  for (int kb = 0; kb < LB / 3; ++kb) {
+    float* P = Pb + (kb & 1) * LB * 4;
+    if (tx == kb && ty >= kb) {
+#pragma unroll
+      for (int r = 0; r < 3; ++r) *(f32x4*)&P[(3 * ty + r) * 4] = f32x4{a[r][0], a[r][1], a[r][2], 0.f};
     }
+    __syncthreads();
+    if (!lower || tx < kb || ty < kb) continue;
+    // the pivot block's factor (every thread its own copy)
+    // (one 16-byte LDS read per panel row: the 24 scalar reads of a step were most of its time)
+    const f32x4 pr0 = *(const f32x4*)&P[(3 * kb) * 4], pr1 = *(const f32x4*)&P[(3 * kb + 1) * 4], pr2 = *(const f32x4*)&P[(3 * kb + 2) * 4];
+    const float p00 = pr0[0], p10 = pr1[0], p11 = pr1[1], p20 = pr2[0], p21 = pr2[1], p22 = pr2[2];
+    // (v_rsq_f32, 1 ulp: sqrtf and the IEEE division expand to ~25 dependent instructions each, and this chain -- three of each --
+    // is on every step's critical path)
+    const float d00 = fmaxf(p00, floor_), i00 = __builtin_amdgcn_rsqf(d00), l00 = d00 * i00;
+    const float l10 = p10 * i00, l20 = p20 * i00;
+    const float d11 = fmaxf(p11 - l10 * l10, floor_), i11 = __builtin_amdgcn_rsqf(d11), l11 = d11 * i11;
+    const float l21 = (p21 - l20 * l10) * i11;
+    const float d22 = fmaxf(p22 - l20 * l20 - l21 * l21, floor_), i22 = __builtin_amdgcn_rsqf(d22), l22 = d22 * i22;
+    if (ty == kb) {                                    // (then tx == kb: the pivot block itself)
+      float* d = A + (3 * kb) * LDJ + 3 * kb;
+      d[0] = l00;
+      d[LDJ] = l10, d[LDJ + 1] = l11;
+      d[2 * LDJ] = l20, d[2 * LDJ + 1] = l21, d[2 * LDJ + 2] = l22;
+      continue;
+    }
+    float li[3][3];                                    // my rows of the panel: L[3 ty + r][3 kb + m]
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const f32x4 qv = *(const f32x4*)&P[(3 * ty + r) * 4];
+      const float q0 = qv[0], q1 = qv[1], q2 = qv[2];
+      li[r][0] = q0 * i00;
+      li[r][1] = (q1 - li[r][0] * l10) * i11;
+      li[r][2] = (q2 - li[r][0] * l20 - li[r][1] * l21) * i22;
+    }
+    if (tx == kb) {                                    // panel owner: these are final
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int m = 0; m < 3; ++m) A[(3 * ty + r) * LDJ + 3 * kb + m] = li[r][m];
+      continue;
+    }
+    float lj[3][3];                                    // my columns' rows of the panel: L[3 tx + c][3 kb + m]
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const f32x4 qv = *(const f32x4*)&P[(3 * tx + c) * 4];
+      const float q0 = qv[0], q1 = qv[1], q2 = qv[2];
+      lj[c][0] = q0 * i00;
+      lj[c][1] = (q1 - lj[c][0] * l10) * i11;
+      lj[c][2] = (q2 - lj[c][0] * l20 - lj[c][1] * l21) * i22;
+    }
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) a[r][c] -= li[r][0] * lj[c][0] + li[r][1] * lj[c][1] + li[r][2] * lj[c][2];
   }
   __syncthreads();
-  float sc[3][3];
+  if (ty <= tx) {                                      // zero above the diagonal (the inverse below reads full rows)
 #pragma unroll
-  for (int a = 0; a < 3; ++a)
+    for (int r = 0; r < 3; ++r)
 #pragma unroll
-    for (int b = 0; b < 3; ++b) {              // L[i][k] = A[i][k] / sqrt(piv_k); the diagonal is read by everybody first
-      const int i = ty + 32 * a, kk = tx + 32 * b;
-      sc[a][b] = i > kk ? A[i * LDJ + kk] * rsqrtf(fmaxf(A[kk * LDJ + kk], floor_)) : (i == kk ? sqrtf(fmaxf(A[kk * LDJ + kk], floor_)) : 0.f);
-    }
-  __syncthreads();
-#pragma unroll
-  for (int a = 0; a < 3; ++a)
-#pragma unroll
-    for (int b = 0; b < 3; ++b) A[(ty + 32 * a) * LDJ + tx + 32 * b] = sc[a][b];      // (upper triangle zeroed: the inverse below reads full rows)
+      for (int c = 0; c < 3; ++c)
+        if (ty < tx || c > r) A[(3 * ty + r) * LDJ + 3 * tx + c] = 0.f;
+  }
   __syncthreads();
 }
 
 // One level of the recursive inverse of a lower-triangular matrix: for every pair of adjacent M x M diagonal blocks whose inverses
-// X11, X22 are in place,  X21 = -X22 (L21 X11).  T: scratch of the same shape.
+// X11, X22 are in place,  X21 = -X22 (L21 X11).  T: scratch of the same shape.  A thread owns a 3 x 3 block of the product (18 LDS
+// reads per 27 multiply-adds instead of 2 per 1).
 template <int M>
 __device__ void tri_inverse_level(const float* Lm, float* X, float* T) {
-  const int tid = threadIdx.x, nt = blockDim.x;
-  constexpr int NPAIR = LB / (2 * M);
-  for (int o = tid; o < NPAIR * M * M; o += nt) {           // T = L21 X11  (X11 lower triangular: k >= j)
-    const int p = o / (M * M), rem = o - p * M * M, i = rem / M, j = rem - i * M;
-    const int r0 = (2 * p + 1) * M, c0 = 2 * p * M;
-    float acc = 0.f;
-    for (int k = j; k < M; ++k) acc = fmaf(Lm[(r0 + i) * LDJ + c0 + k], X[(c0 + k) * LDJ + c0 + j], acc);
-    T[(r0 + i) * LDJ + c0 + j] = acc;
+  const int tid = threadIdx.x;
+  constexpr int NPAIR = LB / (2 * M), MB = M / 3, NBLK = NPAIR * MB * MB;
+  static_assert(NBLK <= 1024, "one pass of the thread block");
+  const bool on = tid < NBLK;
+  const int p = tid / (MB * MB), rem = tid - p * MB * MB, bi = rem / MB, bj = rem - bi * MB;
+  const int r0 = (2 * p + 1) * M, c0 = 2 * p * M;
+  if (on) {                                             // T = L21 X11  (X11 lower triangular: k >= the column)
+    float acc[3][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+    for (int kb = bj; kb < MB; ++kb) {
+      float l[3][3], x[3][3];
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int m = 0; m < 3; ++m) {
+          l[r][m] = Lm[(r0 + 3 * bi + r) * LDJ + c0 + 3 * kb + m];
+          x[r][m] = X[(c0 + 3 * kb + r) * LDJ + c0 + 3 * bj + m];
+        }
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) acc[r][c] += l[r][0] * x[0][c] + l[r][1] * x[1][c] + l[r][2] * x[2][c];
+    }
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) T[(r0 + 3 * bi + r) * LDJ + c0 + 3 * bj + c] = acc[r][c];
   }
   __syncthreads();
-  for (int o = tid; o < NPAIR * M * M; o += nt) {           // X21 = -X22 T   (X22 lower triangular: k <= i)
-    const int p = o / (M * M), rem = o - p * M * M, i = rem / M, j = rem - i * M;
-    const int r0 = (2 * p + 1) * M, c0 = 2 * p * M;
-    float acc = 0.f;
-    for (int k = 0; k <= i; ++k) acc = fmaf(X[(r0 + i) * LDJ + r0 + k], T[(r0 + k) * LDJ + c0 + j], acc);
-    X[(r0 + i) * LDJ + c0 + j] = -acc;
+  if (on) {                                             // X21 = -X22 T   (X22 lower triangular: k <= the row)
+    float acc[3][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+    for (int kb = 0; kb <= bi; ++kb) {
+      float x[3][3], t[3][3];
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int m = 0; m < 3; ++m) {
+          x[r][m] = X[(r0 + 3 * bi + r) * LDJ + r0 + 3 * kb + m];
+          t[r][m] = T[(r0 + 3 * kb + r) * LDJ + c0 + 3 * bj + m];
+        }
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) acc[r][c] += x[r][0] * t[0][c] + x[r][1] * t[1][c] + x[r][2] * t[2][c];
+    }
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) X[(r0 + 3 * bi + r) * LDJ + c0 + 3 * bj + c] = -acc[r][c];
   }
   __syncthreads();
 }
@@ -884,7 +977,7 @@ __global__ __launch_bounds__(1024) void lr_orth_kernel(float* __restrict__ Sg, f
   }
   __syncthreads();
   LR_STAMP(1, 1);
-  cholesky96(B0, 1e-6f);
+  cholesky96(B0, B1, 1e-6f);
   LR_STAMP(1, 2);
   tri_inverse96(B0, B1, B2);                     // B1 = L^-1
   LR_STAMP(1, 3);
@@ -984,7 +1077,7 @@ __global__ __launch_bounds__(1024) void lr_ritz_kernel(float* __restrict__ Pg, f
   }
   __syncthreads();
   LR_STAMP(2, 3);
-  cholesky96(B0, 1e-6f);                       // S'n = L L^T
+  cholesky96(B0, B3, 1e-6f);                   // S'n = L L^T (B3 = S is dead: panel scratch)
   LR_STAMP(2, 4);
   tri_inverse96(B0, B3, B2);                   // B3 = L^-1 (B2 = S' is dead: scratch)
   LR_STAMP(2, 5);
@@ -1124,7 +1217,7 @@ extern "C" int64_t dkd_lowrank_chain_zero_bytes(int32_t L, int32_t Dt) { return 
 extern "C" int dkd_lowrank_chain(const float* G, float* V, int32_t L, int32_t Dt, int32_t n_mult, int32_t ritz_sweeps, int32_t rank, void* v_hi,
                                  void* v_lo, float* evals, void* ws, void* stream) {
   DKD_CHECK_ARG(G && V && ws, "lowrank_chain: null operand");
-  DKD_CHECK_ARG(L > 0 && Dt >= 128 && Dt % 32 == 0 && Dt <= 2048, "lowrank_chain: Dt=%d must be a multiple of 32 in [128, 2048]", Dt);
+  DKD_CHECK_ARG(L > 0 && Dt >= 128 && Dt % 64 == 0 && Dt <= 2048, "lowrank_chain: Dt=%d must be a multiple of 64 in [128, 2048]", Dt);
   DKD_CHECK_ARG(n_mult >= 1 && n_mult <= 64, "lowrank_chain: n_mult %d", n_mult);
   DKD_CHECK_ARG(ritz_sweeps >= 0 && ritz_sweeps <= 32, "lowrank_chain: ritz_sweeps %d", ritz_sweeps);
   DKD_CHECK_ARG(!v_hi || (v_lo && rank > 0 && rank <= LB), "lowrank_chain: hi/lo output needs 0 < rank <= %d", LB);

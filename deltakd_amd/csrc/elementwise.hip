@@ -189,7 +189,11 @@ __global__ void adamw_gated_kernel(float* __restrict__ p, const float* __restric
 //   mixup : x_b <- lam s_b + (1-lam) s_{B-1-b}        cutmix: the box [yl,yh) x [xl,xh) of x_b <- that of s_{B-1-b}, the rest s_b
 // src != x (dkd_mixup_to): the same bytes moved as in place, and the caller's batch survives -- a batch that stays resident in HBM across
 // steps needs no copy per step to be mixed again.
-__global__ void mixup_kernel(const float* src, float* x, int B, int C, int H, int W, float lam, int cutmix, int yl, int yh, int xl, int xh) {
+// PATCHES (dkd_mixup_to_patches): the mix is ALSO written as the bf16 patch matrix [B * gh * gw, C * p * p] the patch-embedding GEMMs of
+// student and teacher read (im2col_kernel's layout): the batch is read once, no separate gather pass over the mixed images.
+template <bool PATCHES>
+__global__ void mixup_kernel(const float* src, float* x, int B, int C, int H, int W, float lam, int cutmix, int yl, int yh, int xl, int xh,
+                             bf16_t* __restrict__ patches, int p) {
   const long per = (long)C * H * W;
   const long total4 = (long)(B / 2) * per / 4;
   for (long t = blockIdx.x * (long)blockDim.x + threadIdx.x; t < total4; t += (long)gridDim.x * blockDim.x) {
@@ -219,6 +223,14 @@ __global__ void mixup_kernel(const float* src, float* x, int B, int C, int H, in
     }
     *(f32x4*)pa = na;
     *(f32x4*)pb = nc;
+    if (PATCHES) {
+      const int px0 = (int)(off % W), py0 = (int)((off / W) % H), ch = (int)(off / ((long)W * H));
+      const int gw = W / p, gh = H / p, K = C * p * p;
+      const long rowa = ((long)b * gh + py0 / p) * gw + px0 / p, rowb = ((long)(B - 1 - b) * gh + py0 / p) * gw + px0 / p;
+      const int k = ch * p * p + (py0 % p) * p + (px0 % p);
+      *(uint2*)(patches + rowa * K + k) = uint2{pack2bf(na[0], na[1]), pack2bf(na[2], na[3])};
+      *(uint2*)(patches + rowb * K + k) = uint2{pack2bf(nc[0], nc[1]), pack2bf(nc[2], nc[3])};
+    }
   }
 }
 
@@ -380,8 +392,8 @@ extern "C" int dkd_mixup(float* x, int32_t B, int32_t C, int32_t H, int32_t W, f
                          int32_t xh, void* stream) {
   DKD_CHECK_ARG(x && B > 0 && B % 2 == 0, "mixup: batch size should be even (B=%d)", B);
   DKD_CHECK_ARG(W % 4 == 0, "mixup: W=%d must be a multiple of 4", W);
-  hipLaunchKernelGGL(mixup_kernel, dim3(grid_for((long)(B / 2) * C * H * W / 4)), dim3(256), 0, as_stream(stream), x, x, B, C, H, W, lam, cutmix, yl,
-                     yh, xl, xh);
+  hipLaunchKernelGGL(mixup_kernel<false>, dim3(grid_for((long)(B / 2) * C * H * W / 4)), dim3(256), 0, as_stream(stream), x, x, B, C, H, W, lam, cutmix, yl,
+                     yh, xl, xh, (bf16_t*)nullptr, 1);
   DKD_CHECK_LAUNCH("mixup");
   return DKD_OK;
 }
@@ -392,9 +404,21 @@ extern "C" int dkd_mixup_to(const float* src, float* dst, int32_t B, int32_t C, 
   DKD_CHECK_ARG(W % 4 == 0, "mixup_to: W=%d must be a multiple of 4", W);
   const size_t n = (size_t)B * C * H * W;
   DKD_CHECK_ARG(src == dst || src + n <= dst || dst + n <= src, "mixup_to: src and dst overlap without being the same batch");
-  hipLaunchKernelGGL(mixup_kernel, dim3(grid_for((long)(B / 2) * C * H * W / 4)), dim3(256), 0, as_stream(stream), src, dst, B, C, H, W, lam,
-                     cutmix, yl, yh, xl, xh);
+  hipLaunchKernelGGL(mixup_kernel<false>, dim3(grid_for((long)(B / 2) * C * H * W / 4)), dim3(256), 0, as_stream(stream), src, dst, B, C, H, W, lam,
+                     cutmix, yl, yh, xl, xh, (bf16_t*)nullptr, 1);
   DKD_CHECK_LAUNCH("mixup_to");
+  return DKD_OK;
+}
+
+extern "C" int dkd_mixup_to_patches(const float* src, float* dst, void* patches, int32_t p, int32_t B, int32_t C, int32_t H, int32_t W,
+                                    float lam, int32_t cutmix, int32_t yl, int32_t yh, int32_t xl, int32_t xh, void* stream) {
+  DKD_CHECK_ARG(src && dst && patches && B > 0 && B % 2 == 0, "mixup_to_patches: batch size should be even (B=%d)", B);
+  DKD_CHECK_ARG(p > 0 && p % 4 == 0 && H % p == 0 && W % p == 0, "mixup_to_patches: patch size %d must be a multiple of 4 dividing H, W", p);
+  const size_t n = (size_t)B * C * H * W;
+  DKD_CHECK_ARG(src + n <= dst || dst + n <= src, "mixup_to_patches: src and dst must not overlap");
+  hipLaunchKernelGGL(mixup_kernel<true>, dim3(grid_for((long)(B / 2) * C * H * W / 4)), dim3(256), 0, as_stream(stream), src, dst, B, C, H, W, lam,
+                     cutmix, yl, yh, xl, xh, (bf16_t*)patches, p);
+  DKD_CHECK_LAUNCH("mixup_to_patches");
   return DKD_OK;
 }
 

@@ -38,6 +38,7 @@ class DataParallel(nn.Module):
                 shadow.optimizer_stepped(bf16_fresh=False)
         self._done = {}
         self._plan = None
+        self._avg_in_collective = None
         self.collectives = 0          # all-reduce calls issued / bytes they carried (bench.py reports them for N > 1)
         self.bytes_reduced = 0
         if optimizer is not None and hasattr(optimizer, "grad_sync"):
@@ -64,8 +65,15 @@ class DataParallel(nn.Module):
         return [flat[i:i + n] for i in range(0, flat.numel(), n)]
 
     def _reduce(self, t):
-        dist.all_reduce(t, group=self.group)
-        t.div_(self.world)
+        # RCCL averages inside the collective (ncclAvg): no division launch behind every bucket; gloo has no
+        # AVG -- the CPU / rehearsal path keeps sum + divide
+        if self._avg_in_collective is None:
+            self._avg_in_collective = dist.get_backend(self.group) == "nccl"
+        if self._avg_in_collective:
+            dist.all_reduce(t, op=dist.ReduceOp.AVG, group=self.group)
+        else:
+            dist.all_reduce(t, group=self.group)
+            t.div_(self.world)
         self.collectives += 1
         self.bytes_reduced += t.numel() * t.element_size()
 

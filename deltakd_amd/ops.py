@@ -625,6 +625,18 @@ def mixup(x, lam, box=None):
     return out
 
 
+def mixup_with_patches(x, lam, box, p):
+    """``mixup`` that also returns the mix as the bf16 patch matrix of ``im2col_patches(out, p)`` (same launch)."""
+    assert x.dtype == F32 and x.is_contiguous() and x.dim() == 4
+    B, Cc, H, W = x.shape
+    yl, yh, xl, xh = box if box is not None else (0, 0, 0, 0)
+    out = torch.empty_like(x)
+    patches = torch.empty(B * (H // p) * (W // p), Cc * p * p, device=x.device, dtype=BF16)
+    check(lib().dkd_mixup_to_patches(ptr(x), ptr(out), ptr(patches), p, B, Cc, H, W, lam, int(box is not None), int(yl), int(yh), int(xl),
+                                     int(xh), stream()), "mixup_to_patches")
+    return out, patches
+
+
 def mixup_targets(labels, num_classes, lam, smoothing):
     assert labels.dtype == torch.int64 and labels.is_contiguous()
     out = torch.empty(labels.shape[0], num_classes, device=labels.device, dtype=F32)

@@ -2,6 +2,8 @@
 ``timm.utils.accuracy`` / ``NativeScaler`` (tools/engine.py:3, tools/train.py:11) and ``timm.data.Mixup`` (tools/train.py:7).
 Host-side plumbing on torch tensors (they work on host or device tensors alike); the arithmetic that matters is in libdkd.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -74,7 +76,7 @@ class Mixup:
     CutMix with probability ``switch_prob`` (random box, lambda corrected to the box area), label-smoothed soft targets."""
 
     def __init__(self, mixup_alpha=1., cutmix_alpha=0., cutmix_minmax=None, prob=1.0, switch_prob=0.5, mode="batch",
-                 correct_lam=True, label_smoothing=0.1, num_classes=1000, inplace=False):
+                 correct_lam=True, label_smoothing=0.1, num_classes=1000, inplace=False, patch_size=16):
         if mode != "batch":
             raise ValueError("deltakd_amd.shims.Mixup implements mode='batch'")
         if cutmix_minmax is not None:
@@ -87,6 +89,10 @@ class Mixup:
         # batch kept resident in HBM can be mixed again next epoch / step without a copy); True overwrites x as timm does.  The reference's
         # loop uses the RETURNED tensor only (tools/engine.py:16-18).  Host tensors are always mixed in place, as in timm.
         self.inplace = inplace
+        # out-of-place device mixes also leave the bf16 patch matrix of the mixed batch for the models' patch embeddings (same launch,
+        # deltakd_amd.vit.register_patches): the gather pass over the mixed images disappears.  None disables; a model with another patch
+        # size simply does not find the matrix and gathers its own.
+        self.patch_size = patch_size
 
     def _params_per_batch(self):
         lam, use_cutmix = 1., False
@@ -121,7 +127,15 @@ class Mixup:
             # lambda / box draws stay on the host's numpy RNG exactly as in timm
             from . import ops
             if lam != 1.:
-                x = ops.mixup_(x, float(lam), box) if self.inplace else ops.mixup(x, float(lam), box)
+                p = self.patch_size
+                if self.inplace:
+                    x = ops.mixup_(x, float(lam), box)
+                elif p and p % 4 == 0 and x.shape[-2] % p == 0 and x.shape[-1] % p == 0 and not os.environ.get("DKD_NO_SHARED_PATCHES"):
+                    from . import vit
+                    x, patches = ops.mixup_with_patches(x, float(lam), box, p)
+                    vit.register_patches(x, p, patches)
+                else:
+                    x = ops.mixup(x, float(lam), box)
             tgt = target.to(device=x.device, dtype=torch.int64).contiguous()
             return x, ops.mixup_targets(tgt, self.num_classes, float(lam), self.label_smoothing)
         if lam != 1.:                       # host tensors (the reference mixes before the H2D copy): plain torch

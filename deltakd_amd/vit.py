@@ -440,6 +440,16 @@ def _shared_patches(img, p):
     return patches
 
 
+def register_patches(img, p, patches):
+    """The bf16 patch matrix of ``img`` produced by somebody else (the Mixup kernel writes it beside the mix) for ``_shared_patches``."""
+    cur = torch.cuda.current_stream(img.device)
+    ev = torch.cuda.Event()
+    ev.record(cur)
+    if id(img) not in _PATCH_CACHE:
+        weakref.finalize(img, _PATCH_CACHE.pop, id(img), None)
+    _PATCH_CACHE[id(img)] = (weakref.ref(img), (img._version, p, img.data_ptr(), tuple(img.shape)), patches, ev, cur.cuda_stream)
+
+
 def _in_backward_pass():
     """Is the autograd engine executing a graph task on this thread?  (torch._C._current_graph_task_id() is -1 outside one.)"""
     fn = getattr(torch._C, "_current_graph_task_id", None)

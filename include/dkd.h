@@ -249,6 +249,11 @@ int dkd_mixup(float* x, int32_t B, int32_t C, int32_t H, int32_t W, float lam, i
 int dkd_mixup_to(const float* src, float* dst, int32_t B, int32_t C, int32_t H, int32_t W, float lam, int32_t cutmix, int32_t yl, int32_t yh,
                  int32_t xl, int32_t xh, void* stream);
 /* out f32 [B, C] = lam * smooth_onehot(labels[b]) + (1-lam) * smooth_onehot(labels[B-1-b])   (timm mixup_target). */
+/* dkd_mixup_to that ALSO writes the mix as the bf16 patch matrix [B * (H/p) * (W/p), C * p * p] of dkd_im2col_patches (k = c p p + i p + j):
+ * the patch-embedding GEMMs of student and teacher (timm PatchEmbed: Conv2d(3, D, p, p), model/models.py:195) read it, so the mixed batch
+ * is read once and no gather pass runs over it.  p % 4 == 0, p | H, p | W. */
+int dkd_mixup_to_patches(const float* src, float* dst, void* patches, int32_t p, int32_t B, int32_t C, int32_t H, int32_t W, float lam,
+                         int32_t cutmix, int32_t yl, int32_t yh, int32_t xl, int32_t xh, void* stream);
 int dkd_mixup_targets(const int64_t* labels, float* out, int32_t B, int32_t C, float lam, float smoothing, void* stream);
 /* ema <- decay * ema + (1 - decay) * p over a flat parameter buffer (timm ModelEma [3P], tools/engine.py:68-69). */
 int dkd_ema_update(float* ema, const float* p, int64_t n, float decay, void* stream);

@@ -735,6 +735,38 @@ def test_patch_matrix_is_shared_between_teacher_and_student(ops, monkeypatch):
         assert torch.equal(b3, s(x.clone()))
 
 
+@pytest.mark.parametrize("box", [None, (30, 150, 16, 200), (0, 224, 0, 224)])
+def test_mixup_also_writes_the_patch_matrix(ops, box):
+    """dkd_mixup_to_patches: the mix and, from the same launch, its bf16 patch matrix -- bit-identical to dkd_mixup_to followed by
+    dkd_im2col_patches; and the Mixup shim hands that matrix to the models (no im2col launch in a training step with mixup on)."""
+    x = rnd(6, 3, 224, 224, seed=12)
+    ref = ops.mixup(x, 0.37, box)
+    out, patches = ops.mixup_with_patches(x, 0.37, box, 16)
+    assert torch.equal(out, ref) and torch.equal(patches, ops.im2col_patches(ref, 16))
+    from deltakd_amd import shims, vit
+    import numpy as np
+    np.random.seed(3)
+    calls = []
+    real = ops.im2col_patches
+    import pytest as _pt
+    mp = _pt.MonkeyPatch()
+    try:
+        mp.setattr(vit.ops, "im2col_patches", lambda img, p: (calls.append(1), real(img, p))[1])
+        mix = shims.Mixup(mixup_alpha=0.8, cutmix_alpha=1.0, num_classes=10)
+        xm, _ = mix(x, torch.arange(6, device=dev()) % 10)
+        assert xm is not x
+        torch.manual_seed(0)
+        m = vit.VisionTransformer(64, 1, 1, 10, False, 0.0, img_size=224, patch_size=16).to(dev()).eval()
+        with torch.no_grad():
+            y = m(xm)
+        assert not calls, "the model should have found the Mixup kernel's patch matrix"
+        mp.setenv("DKD_NO_SHARED_PATCHES", "1")
+        with torch.no_grad():
+            assert torch.equal(y, m(xm)) and len(calls) == 1
+    finally:
+        mp.undo()
+
+
 def test_lowrank_targets_vs_svd(ops):
     """Dt = 768 (subspace iteration + Rayleigh-Ritz path): U_k S_k against torch.linalg.svd on the host, up to column sign.
     Cold start, then a warm-started call on a different batch drawn from the same feature distribution."""

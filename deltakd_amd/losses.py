@@ -248,7 +248,12 @@ class LowRankTargets:
             lo = torch.empty(L, rank, Dt, device=G.device, dtype=BF16)
         if self.ritz is None or self.ritz.shape != (L, b) or self.ritz.device != G.device:
             self.ritz = torch.empty(L, b, device=G.device, dtype=F32)
-        ops.lowrank_chain(G, V, max(1, self.warm_iters), self.ritz_sweeps, self._cws, rank=rank, hi=hi, lo=lo, evals=self.ritz)
+        if Dt % 64 == 0:
+            ops.lowrank_chain(G, V, max(1, self.warm_iters), self.ritz_sweeps, self._cws, rank=rank, hi=hi, lo=lo, evals=self.ritz)
+        else:                       # (a width the chain's 64-wide K groups do not take: the step-by-step launches of rounds 2-4)
+            for _ in range(self.warm_iters - 1):
+                ops.lowrank_step(G, V, 0, self._ws)
+            ops.lowrank_step(G, V, 1, self._ws, rank=rank, hi=hi, lo=lo, evals=self.ritz, ritz_sweeps=self.ritz_sweeps)
         self.calls += 1
         if self.monitor_every > 0 and self.calls % self.monitor_every == 0:
             self.last_residual = self.residual(G, rank)

@@ -879,6 +879,10 @@ extern "C" int dkd_attn_fwd(const void* qkv, void* out, float* lse, int32_t B, i
       return DKD_ERR_HIP;
     }
     n_cu = prop.multiProcessorCount;
+    if (const char* lim = getenv("DKD_CU_LIMIT")) {      // (dev: see gemm.hip)
+      const int v = atoi(lim);
+      if (v >= 8 && v < n_cu) n_cu = v;
+    }
   }
   if (nt >= 8 && B * H >= 2 * n_cu) {    // enough heads per CU for the double-buffered persistent kernel to pay
     const int smem_ring = 2 * 2 * nt * 16 * 128;
@@ -924,6 +928,10 @@ extern "C" int dkd_attn_bwd(const void* qkv, const void* out, const void* dout, 
       return DKD_ERR_HIP;
     }
     n_cu = prop.multiProcessorCount;
+    if (const char* lim = getenv("DKD_CU_LIMIT")) {      // (dev: see gemm.hip)
+      const int v = atoi(lim);
+      if (v >= 8 && v < n_cu) n_cu = v;
+    }
   }
   static const bool no_head = getenv("DKD_ATTN_BWD_SPLIT") != nullptr;
   if ((nt == 8 || nt == 14) && nbh >= n_cu && !no_head) {     // one persistent workgroup per CU, the whole head in LDS

@@ -1799,15 +1799,21 @@ extern "C" int dkd_gemm_nt(const DkdGemm* gp, void* stream) {
       return DKD_ERR_HIP;
     }
     n_cu = prop.multiProcessorCount & ~7;
+    // (dev, DKD_CU_LIMIT=n: persistent kernels on n workgroups -- two half-batch teacher pipelines side by side on disjoint halves of
+    // the chip, tools_dev/teacher_halves_probe.py)
+    if (const char* lim = getenv("DKD_CU_LIMIT")) {
+      const int v = atoi(lim) & ~7;
+      if (v >= 8 && v < n_cu) n_cu = v;
+    }
   }
   const long t256 = g.N % 256 == 0 ? (long)cdiv(g.M, 256) * (g.N / 256) : 0;
-  bool wide = ring_ok && t256 >= 1024;
+  bool wide = ring_ok && t256 >= 4 * n_cu;
   // N = 768 (teacher proj / fc2): 594 tiles of 256 x 256 are 2.3 rounds on 256 CUs.  The whole rounds go to the persistent kernel,
   // the remaining rows to the 128 x 128 kernel (a second call on the row range behind them).
   const bool fast3w = vec_ok && g.epi == (DKD_EPI_BIAS | DKD_EPI_RESID | DKD_EPI_OUT_F32) && !g.rowscale && g.amap.rpg == 0 &&
                       g.cmap.rpg == 0 && g.rmap.rpg == 0 && !g.preact && !(g.tap && (g.epi & DKD_EPI_TAP_F32));
   static const int split_k_min = getenv("DKD_SPLIT_KMIN") ? atoi(getenv("DKD_SPLIT_KMIN")) : 1536;     // (dev: A/B of proj on this path)
-  if (!wide && ring_ok && fast3w && t256 >= 2 * n_cu && t256 < 1024 && g.K >= split_k_min) {   // fc2: 330 -> 305 us; proj (K = 768): no gain
+  if (!wide && ring_ok && fast3w && t256 >= 2 * n_cu && t256 < 4 * n_cu && g.K >= split_k_min) {   // fc2: 330 -> 305 us; proj (K = 768): no gain
     const int tn = g.N / 256;
     const int panels1 = (int)((t256 / n_cu) * n_cu / tn);           // whole rounds' worth of 256-row panels
     const int M1 = panels1 * 256;

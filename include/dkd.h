@@ -448,6 +448,7 @@ int dkd_lowrank_step(const float* G, float* V, int32_t L, int32_t Dt, int32_t mo
  * (multiplies per stage 1, 2, 2, ..., 1).  Outputs as dkd_lowrank_step modes 1 / 3: V in place, evals f32 [L, 96] (may be null),
  * v_hi / v_lo bf16 [L, rank, Dt] (may be null).  ws: dkd_lowrank_chain_workspace_bytes(L, Dt) bytes, 256-byte aligned, whose first
  * dkd_lowrank_chain_zero_bytes(L, Dt) bytes must be ZERO when the first call is made (every call leaves them zero again).
+ * Dt % 64 == 0, 128 <= Dt <= 2048 (other widths: dkd_lowrank_step).
  * Replaces: torch.linalg.svd at model/loss.py:321. */
 int64_t dkd_lowrank_chain_workspace_bytes(int32_t L, int32_t Dt);
 int64_t dkd_lowrank_chain_zero_bytes(int32_t L, int32_t Dt);

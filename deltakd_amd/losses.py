@@ -43,11 +43,14 @@ class _LogitLossFn(torch.autograd.Function):
                                            z_kd=None if z_kd is None else z_kd.contiguous().float(),
                                            z_t=None if z_t is None else z_t.contiguous().float(), tau=tau, w_base=w_base, w_kd=w_kd)
         ctx.dz, ctx.dz_kd = dz, dz_kd
+        ctx.set_materialize_grads(False)           # (no zeros tensor for the non-differentiable second output in backward)
         ctx.mark_non_differentiable(losses)
         return losses[2], losses      # losses = (base, distill, w_base * base + w_kd * distill, w_base * base, w_kd * distill)
 
     @staticmethod
     def backward(ctx, g, _):
+        if g is None:
+            return (None,) * 9
         dz = ctx.dz * g
         dz_kd = None if ctx.dz_kd is None else ctx.dz_kd * g
         return dz, dz_kd, None, None, None, None, None, None, None
@@ -144,6 +147,55 @@ def align_mse_term(tap, align, shadow, target, tmap, scale, npre, mask=None):
         ops.mse_loss(s, target, loss, scale / (M * D), M=M, tmap=tmap, mask=mask, grad_out=da)
         return da
     return _AlignTermFn.apply(tap, align, shadow, npre, cb)
+
+
+class _LrkdTermsFn(torch.autograd.Function):
+    """sum_i w_i mean((align_i(tap_i[:, npre:]) - target_i)^2) for the LRKD layers as ONE autograd node (model/loss.py:326-329 sums three
+    terms): the three fused loss kernels add into one loss slot, the three gradients sit in one buffer (one scale launch by the upstream
+    device scalar, one fill of the prefix rows of the three tap gradients).  Per layer the launches are those of ``_AlignTermFn``; what
+    disappears are two scalar adds, two slot fills, two scale and two prefix-row-fill launches per step."""
+
+    @staticmethod
+    def forward(ctx, sm, npre, targets, weights, *taps):
+        L = len(taps)
+        B, N, Ds = taps[0].shape
+        P = N - npre
+        M = B * P
+        shadow = sm._shadow
+        aligns = [sm.align[i] for i in range(L)]
+        Dt = aligns[0].out_features
+        Kp = _pad64(Dt)
+        assert all(t.shape == taps[0].shape for t in taps) and all(a.out_features == Dt for a in aligns)
+        loss = torch.zeros(1, device=taps[0].device, dtype=F32)
+        das = torch.zeros(L, M, Kp, device=loss.device, dtype=BF16) if Kp != Dt else torch.empty(L, M, Kp, device=loss.device, dtype=BF16)
+        tap2s = []
+        for i in range(L):
+            tap2 = taps[i].reshape(B * N, Ds)
+            s = ops.gemm_nt(tap2, shadow.get(aligns[i].weight), M=M, amap=strip_map(N, npre), bias=aligns[i].bias, out_f32=True)
+            tgt = targets[i] if targets[i].stride(-1) == 1 else targets[i].contiguous()
+            ops.mse_loss(s, tgt, loss, float(weights[i]) / (M * Dt), M=M, tmap=IDENT, grad_out=das[i])
+            tap2s.append(tap2)
+        ctx.sm, ctx.aligns, ctx.tap2s, ctx.das, ctx.dims = sm, aligns, tap2s, das, (L, B, N, Ds, npre, M, Dt, Kp)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        L, B, N, Ds, npre, M, Dt, Kp = ctx.dims
+        das, shadow = ctx.das, ctx.sm._shadow
+        if das.numel() % 8 == 0 and g.dtype == F32 and g.is_cuda:
+            ops.scale_bf16_(das, g.reshape(1))          # (f32 product with the upstream device scalar, all three gradients in one launch)
+        else:
+            das.mul_(g)
+        smap = strip_map(N, npre)
+        dtaps = torch.empty(L, B, N, Ds, device=das.device, dtype=BF16)
+        if npre:
+            dtaps[:, :, :npre].zero_()                  # (the GEMMs below write every patch row; only the prefix rows need zeros)
+        for i in range(L):
+            a = ctx.aligns[i]
+            ops.gemm_tn(das[i], ctx.tap2s[i], ensure_grad(a.weight), M=M, N1=Dt, bmap=smap, colsum=ensure_grad(a.bias))
+            ops.gemm_nt(das[i], shadow.get(a.weight, transposed=True, pad_k_to=Kp), out=dtaps[i].view(B * N, Ds), cmap=smap)
+        ctx.das = ctx.tap2s = None
+        return (None, None, None, None) + tuple(dtaps[i] for i in range(L))
 
 
 class LowRankTargets:
@@ -349,12 +401,16 @@ def lrkd_loss(teacher_features, student_features, rank=10, alpha=0.1, beta=0.1, 
             total = term if total is None else total + term
         return total
     sm = _unwrap(student_model)
-    total = None
     if targets is None:
         targets = (solver or LowRankTargets())(list(teacher_features), npre_t, rank)
+    taps = [student_features[i] for i in range(3)]
+    same = all(t.shape == taps[0].shape and t.dtype == BF16 and t.is_cuda for t in taps) and \
+        len({sm.align[i].out_features for i in range(3)}) == 1
+    if same and not os.environ.get("DKD_LRKD_SEPARATE_TERMS"):
+        return _LrkdTermsFn.apply(sm, npre_s, list(targets[:3]), (float(alpha), float(beta), float(gamma)), *taps)
+    total = None                                     # (layers of different shapes: one node per term, as in rounds 1-4)
     for i, w in enumerate((alpha, beta, gamma)):
-        tgt = targets[i]
-        term = align_mse_term(student_features[i], sm.align[i], sm._shadow, tgt, IDENT, float(w), npre_s)
+        term = align_mse_term(student_features[i], sm.align[i], sm._shadow, targets[i], IDENT, float(w), npre_s)
         total = term if total is None else total + term
     return total
 

@@ -781,10 +781,12 @@ class _EmbedFn(torch.autograd.Function):
         dxb = ops.scale_cast_bf16(g, M=B * P, xmap=strip_map(N, npre))
         w = m.patch_embed.proj.weight
         ops.gemm_tn(dxb, ctx.patches, ensure_grad(w).view(D, -1), colsum=ensure_grad(m.patch_embed.proj.bias))
-        dtok = torch.zeros(npre, D, device=g.device, dtype=F32)
-        ops.embed_bwd(g, dtok, ensure_grad(m.pos_embed).view(N, D), B, N, D, npre)
-        ensure_grad(m.cls_token).view(-1).add_(dtok[0])
-        if npre == 2:
+        if npre == 1:                               # one prefix token: the kernel adds straight into cls_token.grad
+            ops.embed_bwd(g, ensure_grad(m.cls_token).view(1, D), ensure_grad(m.pos_embed).view(N, D), B, N, D, npre)
+        else:
+            dtok = torch.zeros(npre, D, device=g.device, dtype=F32)
+            ops.embed_bwd(g, dtok, ensure_grad(m.pos_embed).view(N, D), B, N, D, npre)
+            ensure_grad(m.cls_token).view(-1).add_(dtok[0])
             ensure_grad(m.dist_token).view(-1).add_(dtok[1])
         ctx.patches = None
         return None, None, None
@@ -912,7 +914,20 @@ class VisionTransformer(nn.Module):
         pos = self.pos_embed.view(N, D)
         ops.gemm_nt(patches, self._shadow.get(self.patch_embed.proj.weight), out=x, bias=self.patch_embed.proj.bias,
                     cmap=strip_map(N, npre), resid=pos, rmap=RowMap(P, 0, npre))
-        tok = self.cls_token.view(1, D) if npre == 1 else torch.cat([self.cls_token.view(1, D), self.dist_token.view(1, D)], 0)
+        if npre == 1:
+            tok = self.cls_token.view(1, D)
+        else:
+            # [cls; dist] as one [2, D] matrix.  For a FROZEN model (the teacher) it is built once per token version; a trainable
+            # model's tokens are updated in place by the optimizer kernels (no version bump), so there it is rebuilt every call.
+            frozen = not self.cls_token.requires_grad and not self.dist_token.requires_grad
+            key = (self.cls_token._version, self.dist_token._version, self.cls_token.data_ptr(), self.dist_token.data_ptr())
+            hit = _rt(self).get("prefix_tok") if frozen else None
+            if hit is None or hit[0] != key:
+                tok = torch.cat([self.cls_token.view(1, D), self.dist_token.view(1, D)], 0)
+                if frozen:
+                    _rt(self)["prefix_tok"] = (key, tok)
+            else:
+                tok = hit[1]
         ops.prefix_tokens_fwd(x, tok.detach().contiguous(), pos, B, N, D, npre)
         return x, patches
 

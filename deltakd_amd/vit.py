@@ -453,7 +453,9 @@ def register_patches(img, p, patches):
 def _in_backward_pass():
     """Is the autograd engine executing a graph task on this thread?  (torch._C._current_graph_task_id() is -1 outside one.)"""
     fn = getattr(torch._C, "_current_graph_task_id", None)
-    return fn is not None and fn() != -1
+    if fn is None:                # a torch without the accessor: assume we might be (pending gradients are then flushed, never lost)
+        return True
+    return fn() != -1
 
 
 def flush_wgrads(model):

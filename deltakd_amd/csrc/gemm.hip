@@ -484,7 +484,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const DkdGemm g, const 
 // them: they retire under the next tile's first phases.
 // ABL: dev-only ablation bits (build with -DDKD_NT256_ABL=n; results are then wrong, timings are the point): 1 no epilogue,
 // 2 two units per tile, 4 no LDS-DMA in the loop, 8 no barriers, 16 no fragment reads, 32 no MFMAs, 64 LDS-DMA pieces of full 128-byte lines,
-// 128 every second workgroup of an XCD skips its bf16 stores.
+// 128 every second workgroup of an XCD skips its bf16 stores, 256 ordinary instead of streaming stores, 512 the W pieces as plain
+// register loads instead of LDS-DMA.
 // WN: waves along N.  4: the 256 x 256 tile, 8 waves, ring of 5 units, one workgroup per CU (qkv / fc1 of the teacher).
 //     2: a 256 x 128 tile, 4 waves, ring of 3 units (72 KiB), two workgroups per CU -- for N = 768 (proj / fc2), where 256-wide
 //        tiles leave 256 CUs with 2.3 rounds of work; it moves 25 % less operand data through the LDS-DMA path than the
@@ -565,6 +566,7 @@ __global__ __launch_bounds__(128 * WN, WN == 4 ? 1 : 2) void gemm_nt256_kernel(c
   // Issued through inline asm: the compiler orders every LDS read behind a pending LDS-DMA it knows of with vmcnt(0), which would
   // drain the ring at each fragment read; ordering is this kernel's job (counted vmcnt + barrier), and the compiler's own
   // vmcnt bookkeeping for the epilogue's loads can only over-wait because no DMA is issued between such a load and its use.
+  f32x4 abl_junk = {0.f, 0.f, 0.f, 0.f};      // (ablation bit 512 only)
   auto piece = [&](int c, int slot) {
     const bool is_a = c < AP;
     const int row0 = is_a ? w * (256 / NW) + c * 16 : w * 32 + (c - AP) * 16;
@@ -583,7 +585,14 @@ __global__ __launch_bounds__(128 * WN, WN == 4 ? 1 : 2) void gemm_nt256_kernel(c
 #pragma clang diagnostic push
 #pragma clang diagnostic ignored "-Winline-asm"
     if (is_a) asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(dst), "v"(voff), "s"(Ab) : "memory", "m0");
-    else asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(dst), "v"(voff), "s"(Bb) : "memory", "m0");
+    else if (ABL & 512) {
+      // (ablation bit 512: the W pieces as ordinary 16-byte-per-lane loads into a junk register quad -- same bytes, same slots in the
+      // in-order vmcnt queue, no LDS write: is the ~23 B/clk of the LDS-DMA stream the LDS side's or the memory pipeline's?  timings only)
+      // The destination stays LIVE for the whole kernel ("+v" here, consumed behind a vmcnt(0) at the kernel's end): a dead asm-load
+      // destination is handed to another value while the load is in flight (attn192_bwd defect 1 -- and the first build of
+      // this very ablation, which faulted).
+      asm volatile("global_load_dwordx4 %0, %1, %2" : "+v"(abl_junk) : "v"(voff), "s"(Bb) : "memory");
+    } else asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(dst), "v"(voff), "s"(Bb) : "memory", "m0");
 #pragma clang diagnostic pop
   };
   // past the end of the block's work the cursor stays on the last unit: the re-issued pieces land in a slot nobody reads and keep
@@ -866,6 +875,10 @@ __global__ __launch_bounds__(128 * WN, WN == 4 ? 1 : 2) void gemm_nt256_kernel(c
     for (int c = 0; c < PIECES; ++c) piece(c, slot);
     advance_load();
     slot = slot == RING - 1 ? 0 : slot + 1;
+  }
+  if (ABL & 512) {
+    __builtin_amdgcn_s_waitcnt(vmcnt_imm(0));
+    asm volatile("" ::"v"(abl_junk));
   }
 }
 

@@ -222,6 +222,17 @@ def test_c_abi_library_exports_every_declared_symbol():
     assert handle.dkd_block_bwd_workspace_carve(0x10000, 256, 197, D, Hd, ffi.C.byref(gr)) == 0      # pointer arithmetic only
     assert gr.dF == 0x10000 and gr.dT == gr.dF + al(M * D * 2) and gr.ln_ws2 == gr.dF2 + al(M * D * 2) and \
         gr.ln_ws2 + handle.dkd_layernorm_bwd_workspace_bytes(M, D) - 0x10000 == handle.dkd_block_bwd_workspace_bytes(256, 197, D, Hd)
+    # the LRKD chain's scratch (round 5): two 96 x 96 Gram accumulators per layer first (the part that must be zero), two Y buffers, two
+    # transforms, the diagnostics; and its argument checks answer through the error channel without launching anything
+    L, Dt = 3, 768
+    m96 = al(L * 96 * 96 * 4)
+    assert handle.dkd_lowrank_chain_zero_bytes(L, Dt) == 2 * m96
+    assert handle.dkd_lowrank_chain_workspace_bytes(L, Dt) == 4 * m96 + 2 * al(L * Dt * 96 * 4) + al(L * 8)
+    for bad_dt in (96, 160, 4096):        # below the minimum, not a multiple of 64, above the maximum
+        assert handle.dkd_lowrank_chain(0x1000, 0x1000, L, bad_dt, 8, 12, 64, None, None, None, 0x1000, None) == -1
+        assert b"multiple of 64" in handle.dkd_last_error()
+    assert handle.dkd_lowrank_chain(0x1000, 0x1000, L, Dt, 0, 12, 64, None, None, None, 0x1000, None) == -1       # no multiplies
+    assert handle.dkd_lowrank_chain(0x1000, 0x1000, L, Dt, 8, 12, 64, None, None, None, 0x1010, None) == -1       # misaligned scratch
 
 
 def test_checkpoint_helpers_follow_the_reference_wire_format(tmp_path):

@@ -75,7 +75,9 @@ def train_one_epoch(student_model, teacher_model, train_loader, criterion, optim
     # same box, alternating): 18.06 / 18.08 / 18.05 ms per step for 1 / 2 / 3 -- the two streams time-share the CUs, the chain is not
     # what bounds the step -- so the default stays at one group (one batch of taps alive).  Round 4: lrkd asks for TWO
     # (DistillationLoss.prefetch_depth): its low-rank target chain now runs on a stream of its own, and with two groups in flight the
-    # next teacher forward runs beside it (16.95 -> 16.87 ms with the default tracker, 29.3 -> 19.6 ms with --lrkd-exact).
+    # next teacher forward runs beside it (16.95 -> 16.87 ms with round 4's one-step tracker, 29.3 -> 19.6 ms with its converged mode).
+    # Round 5 (converged targets by default, a 1.4 ms chain): one batch of lookahead costs +1.2 ms, three buy nothing over two
+    # (profiles/r05_lrkd_chain_stream_and_lookahead_ab.txt).
     depth = max(1, int(os.environ.get("DKD_LOOKAHEAD", getattr(criterion, "prefetch_depth", 1)))) if prefetch is not None else 1
     args.current_epoch = epoch
     pending = collections.deque()        # fetched batches, in order; with a prefetch hook their teacher work has been started

@@ -445,7 +445,7 @@ class DistillationLoss(nn.Module):
         self._tail_stream = None     # the stream whose work finishes a run_teacher() call (the teacher stream, or lrkd_stream)
         # teacher batches in flight ahead of the student (deltakd_amd.engine): lrkd keeps TWO -- the next batch's teacher forward then runs
         # beside this batch's target chain instead of waiting for the loss that consumes it (measured: the chain's latency leaves the step's
-        # critical path; --lrkd-exact costs +14 % instead of +73 %).  DKD_LOOKAHEAD overrides.
+        # critical path; round 4's converged mode cost +14 % instead of +73 %; round 5's chain of short launches: +2 %).  DKD_LOOKAHEAD overrides.
         self.prefetch_depth = 2 if str(distillation_type).lower() == "lrkd" else 1
 
     def _draw(self, key):

@@ -609,44 +609,37 @@ __global__ __launch_bounds__(256) void lr_mult_kernel(const float* __restrict__ 
   if (flags & LR_GRAM_P)
     for (int idx = tid; idx < LR_ROWS * LB / 4; idx += 256) *(float4*)&Pt[4 * idx] = *(const float4*)&Bsrc[(size_t)m0 * LB + 4 * idx];
   __syncthreads();
-  // thread: rows i = ty + 8 m (m < 12) x columns j = tx + 32 n (n < 3) of the 96 x 96 partial products over this block's 16 rows
-  float s[12][3], p[12][3];
-#pragma unroll
-  for (int m = 0; m < 12; ++m)
-#pragma unroll
-    for (int n = 0; n < 3; ++n) s[m][n] = p[m][n] = 0.f;
+  // The tile's contribution to the 96 x 96 Gram accumulators on the fp32 matrix cores: output tile (i0, j0) = Yt[:, i0..]^T Yt[:, j0..]
+  // over the block's 16 rows = four 16x16x4 steps (A = the transposed tile: lane supplies Yt[k][i0 + lane % 16], B: Yt[k][j0 + lane % 16],
+  // k = 4 step + lane / 16).  S is symmetric: only its tiles on and below the diagonal are formed and added (21 of 36; the consumers
+  // read the lower triangle); P = Y_prev^T Y' needs all 36.  Tiles are dealt round-robin to the four waves.  (VALU form: 4.8 us.)
   const bool want_p = flags & LR_GRAM_P;
-#pragma unroll 2
-  for (int r = 0; r < LR_ROWS; ++r) {
-    float yj[3];
-#pragma unroll
-    for (int n = 0; n < 3; ++n) yj[n] = Yt[r * LB + tx + 32 * n];
-#pragma unroll
-    for (int m = 0; m < 12; ++m) {
-      const float yi = Yt[r * LB + ty + 8 * m];
-#pragma unroll
-      for (int n = 0; n < 3; ++n) s[m][n] = fmaf(yi, yj[n], s[m][n]);
-    }
-    if (want_p) {
-#pragma unroll
-      for (int m = 0; m < 12; ++m) {
-        const float pi = Pt[r * LB + ty + 8 * m];
-#pragma unroll
-        for (int n = 0; n < 3; ++n) p[m][n] = fmaf(pi, yj[n], p[m][n]);
-      }
-    }
-  }
   LR_STAMP(0, 4);
   float* Sl = Sg + (size_t)layer * LB * LB;
   float* Pl = Pg + (size_t)layer * LB * LB;
+  {
+    int t = 0;
+    for (int ti = 0; ti < 6; ++ti)
+      for (int tj = 0; tj < 6; ++tj) {
+        const bool do_s = (flags & LR_GRAM_S) && tj <= ti;
+        if (!do_s && !want_p) continue;
+        if ((t++ & 3) != wv) continue;
+        f32x4 as = {0.f, 0.f, 0.f, 0.f}, ap = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int m = 0; m < 12; ++m)
+        for (int ks = 0; ks < 4; ++ks) {
+          const int r = 4 * ks + q4;
+          const float bj = Yt[r * LB + 16 * tj + c16];
+          if (do_s) as = __builtin_amdgcn_mfma_f32_16x16x4f32(Yt[r * LB + 16 * ti + c16], bj, as, 0, 0, 0);
+          if (want_p) ap = __builtin_amdgcn_mfma_f32_16x16x4f32(Pt[r * LB + 16 * ti + c16], bj, ap, 0, 0, 0);
+        }
 #pragma unroll
-    for (int n = 0; n < 3; ++n) {
-      const int o = (ty + 8 * m) * LB + tx + 32 * n;
-      if (flags & LR_GRAM_S) atomicAdd(&Sl[o], s[m][n]);
-      if (want_p) atomicAdd(&Pl[o], p[m][n]);
-    }
+        for (int i = 0; i < 4; ++i) {
+          const int o = (16 * ti + 4 * q4 + i) * LB + 16 * tj + c16;
+          if (do_s) atomicAdd(&Sl[o], as[i]);
+          if (want_p) atomicAdd(&Pl[o], ap[i]);
+        }
+      }
+  }
   LR_STAMP(0, 5);
 }
 
@@ -818,6 +811,26 @@ __device__ void tri_inverse96(const float* Lm, float* X, float* T) {
   tri_inverse_level<12>(Lm, X, T);
   tri_inverse_level<24>(Lm, X, T);
   tri_inverse_level<48>(Lm, X, T);
+}
+
+// C = op(A) op(B) on 96 x 96 matrices in LDS (row stride LDJ) on the fp32 matrix cores: 36 output tiles of 16 x 16 dealt to the 16 waves,
+// 24 steps of v_mfma_f32_16x16x4_f32 each.  (The VALU form above: ~10 us per product at 1024 threads, LDS-issue-bound.)
+template <bool TRANS_A, bool TRANS_B>
+__device__ void mm96_mfma(const float* A, const float* B, float* C) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, q4 = lane >> 4, c16 = lane & 15;
+  for (int t = wv; t < 36; t += 16) {
+    const int i0 = (t / 6) * 16, j0 = (t % 6) * 16;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
+    for (int k0 = 0; k0 < LB; k0 += 4) {
+      const int k = k0 + q4;
+      const float a = TRANS_A ? A[k * LDJ + i0 + c16] : A[(i0 + c16) * LDJ + k];
+      const float b = TRANS_B ? B[(j0 + c16) * LDJ + k] : B[k * LDJ + j0 + c16];
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) C[(i0 + 4 * q4 + i) * LDJ + j0 + c16] = acc[i];
+  }
 }
 
 // ---- Jacobi, second form: ONE apply pass per round.  The 96 indices sit in 48 adjacent position pairs (2i, 2i+1) and the DATA moves
@@ -1032,7 +1045,7 @@ __global__ __launch_bounds__(1024) void lr_ritz_kernel(float* __restrict__ Pg, f
   }
   __syncthreads();
   if (has_c) {
-    mm96<true, false, LDJ>(B2, B1, B0);          // H = C_prev^T P = V^T G V
+    mm96_mfma<true, false>(B2, B1, B0);          // H = C_prev^T P = V^T G V
     __syncthreads();
   }
   for (int i = tid; i < LB * LB; i += nt) {      // symmetrise H and S in place: one thread per unordered pair
@@ -1041,9 +1054,7 @@ __global__ __launch_bounds__(1024) void lr_ritz_kernel(float* __restrict__ Pg, f
       const float h = 0.5f * (B0[r * LDJ + c] + B0[c * LDJ + r]);
       B0[r * LDJ + c] = h;
       B0[c * LDJ + r] = h;
-      const float sy = 0.5f * (B3[r * LDJ + c] + B3[c * LDJ + r]);
-      B3[r * LDJ + c] = sy;
-      B3[c * LDJ + r] = sy;
+      B3[c * LDJ + r] = B3[r * LDJ + c];         // (S arrives as its lower triangle: lr_mult_kernel adds only the tiles on and below the diagonal)
     }
   }
   // off-diagonals below 1e-7 of the largest Ritz value are fp32 noise of the GEMMs that built H: rotating on them never converges
@@ -1065,9 +1076,9 @@ __global__ __launch_bounds__(1024) void lr_ritz_kernel(float* __restrict__ Pg, f
     B1[r * LDJ + rnk[c]] = B2[c * LDJ + r];
   }
   __syncthreads();
-  mm96<false, false, LDJ>(B3, B1, B0);         // S W
+  mm96_mfma<false, false>(B3, B1, B0);         // S W
   __syncthreads();
-  mm96<true, false, LDJ>(B1, B0, B2);          // S' = W^T S W = (Y W)^T (Y W)
+  mm96_mfma<true, false>(B1, B0, B2);          // S' = W^T S W = (Y W)^T (Y W)
   __syncthreads();
   if (tid < LB) d[tid] = rsqrtf(fmaxf(B2[tid * LDJ + tid], 1e-30f));
   __syncthreads();
@@ -1083,7 +1094,7 @@ __global__ __launch_bounds__(1024) void lr_ritz_kernel(float* __restrict__ Pg, f
   LR_STAMP(2, 5);
   for (int i = tid; i < LB * LB; i += nt) B1[(i / LB) * LDJ + (i % LB)] *= d[i % LB];      // W D^-1
   __syncthreads();
-  mm96<false, true, LDJ>(B1, B3, B2);          // C = W D^-1 L^-T
+  mm96_mfma<false, true>(B1, B3, B2);          // C = W D^-1 L^-T
   __syncthreads();
   for (int i = tid; i < LB * LB; i += nt) Cl[i] = B2[(i / LB) * LDJ + (i % LB)];
   if (info && tid == 0) {

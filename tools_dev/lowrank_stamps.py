@@ -19,7 +19,7 @@ V = torch.linalg.qr(torch.randn(L, Dt, b, device="cuda", generator=g))[0].contig
 ws = ops.lowrank_chain_workspace(L, Dt, G.device)
 fn = ffi.lib().dkd_lr_read_stamps
 fn.restype, fn.argtypes = C.c_int, [C.c_void_p]
-names = {0: ["start", "panel+C+first chunk", "K loop", "C apply + Y out", "gram FMAs", "atomics"],
+names = {0: ["start", "panel+C+first chunk", "K loop", "C apply + Y out", "-", "gram (MFMA) + atomics"],
          1: ["start", "load+scale", "cholesky", "inverse", "write C"],
          2: ["start", "load + H + symmetrise", "jacobi", "-", "sort + S' (2 mm96)", "cholesky", "inverse", "C = W D^-1 L^-T + write"]}
 for n_mult in (8, 8, 8):
@@ -32,7 +32,9 @@ for n_mult in (8, 8, 8):
     for k, nm in names.items():
         n = len(nm)
         d = [(st[k, i] - st[k, i - 1]) / 100.0 for i in range(1, n if k != 2 else 7)]
-        lab = [x for x in nm[1:] if x != "-"] if k == 2 else nm[1:]
+        if k != 2:
+            d = [v for a, v in zip(nm[1:], d) if a != "-"]
+        lab = [x for x in nm[1:] if x != "-"]
         print(("lr_mult", "lr_orth", "lr_ritz")[k], f"total {(st[k, (n - 1) if k != 2 else 6] - st[k, 0]) / 100.0:.1f} us:",
               ", ".join(f"{a} {v:.1f}" for a, v in zip(lab, d)), f"(jacobi sweeps {sweeps})" if k == 2 else "")
     print()

@@ -1101,11 +1101,17 @@ constexpr int TN_TILE = 64 * TN_LD;        // 18 KiB per operand tile
 __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, float* C,
                                                          int M, int N1, int N2, int lda, int ldb, int ldc, DkdRowMap amap,
                                                          DkdRowMap bmap, int kt_per_split, float* __restrict__ a_colsum,
-                                                         int upper_only, int conv_hw = 0, int conv_dy = 0, int conv_dx = 0) {
+                                                         int upper_only, int conv_hw = 0, int conv_dy = 0, int conv_dx = 0,
+                                                         long batch_stride_ab = 0, long batch_stride_c = 0) {
   // conv_hw > 0: weight gradient of a 3 x 3 / pad 1 convolution, tap = blockIdx.z -- the B row paired with reduction index m is the
   // input pixel m + dy * hw + dx when it lies inside the image, zeros otherwise (no im2col matrix); the tap's [N1, N2] block of
   // C = dW[N1][9][N2] starts at column tap * N2
   const int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  if (conv_hw == 0 && bz > 0) {           // batched problems of one shape (dkd_gram_batched): operands / results at constant strides
+    A += (size_t)bz * batch_stride_ab;
+    B += (size_t)bz * batch_stride_ab;
+    C += (size_t)bz * batch_stride_c;
+  }
   if (conv_hw > 0) {
     conv_dy = bz / 3 - 1;
     conv_dx = bz % 3 - 1;
@@ -2207,5 +2213,26 @@ extern "C" int dkd_gram(const void* A, float* C, int32_t M, int32_t N, int32_t l
   hipLaunchKernelGGL(gemm_tn_kernel, dim3(tiles, splits), dim3(256), 0, as_stream(stream), (const bf16_t*)A, (const bf16_t*)A, C, M, N, N,
                      lda, lda, ldc, amap, amap, per, (float*)nullptr, 1);
   DKD_CHECK_LAUNCH("gram");
+  return DKD_OK;
+}
+
+// L Gram matrices of one shape in ONE launch (the LRKD targets' three teacher taps): A_l = A + l stride_a (elements), C_l = C + l
+// stride_c.  The tile pairs of all L problems share the launch's one round of workgroups, so every workgroup walks an L times longer
+// K range and the f32 atomics of the partial tiles shrink L-fold (three launches: 3 x 504 partial tiles of 64 KB; one: 504).
+extern "C" int dkd_gram_batched(const void* A, int64_t stride_a, float* C, int64_t stride_c, int32_t L, int32_t M, int32_t N, int32_t lda,
+                                int32_t ldc, DkdRowMap amap, void* stream) {
+  DKD_CHECK_ARG(A && C && M > 0 && N > 0 && L > 0 && L <= 64, "gram_batched: bad operand");
+  DKD_CHECK_ARG(lda % 8 == 0 && ((uintptr_t)A & 15) == 0 && stride_a % 8 == 0, "gram_batched: rows of A must be 16-byte aligned (lda=%d)", lda);
+  const int KT = cdiv(M, 64), T = cdiv(N, 128);
+  const int tiles = T * (T + 1) / 2;
+  int splits = 512 / (tiles * L);
+  if (splits < 1) splits = 1;
+  if (splits > cdiv(KT, 4)) splits = cdiv(KT, 4);
+  if (splits < 1) splits = 1;
+  const int per = cdiv(KT, splits);
+  splits = cdiv(KT, per);
+  hipLaunchKernelGGL(gemm_tn_kernel, dim3(tiles, splits, L), dim3(256), 0, as_stream(stream), (const bf16_t*)A, (const bf16_t*)A, C, M, N, N,
+                     lda, lda, ldc, amap, amap, per, (float*)nullptr, 1, 0, 0, 0, (long)stride_a, (long)stride_c);
+  DKD_CHECK_LAUNCH("gram_batched");
   return DKD_OK;
 }

@@ -344,8 +344,14 @@ class LowRankTargets:
         smap = strip_map(N, npre)
         Ts = [t.reshape(B * N, Dt) for t in taps]
         G = torch.zeros(len(Ts), Dt, Dt, device=Ts[0].device, dtype=F32)
-        for i, T in enumerate(Ts):
-            ops.gram(T, G[i], M=B * P, amap=smap, mirror=False)     # upper-triangular tiles only
+        step = (Ts[1].data_ptr() - Ts[0].data_ptr()) // 2 if len(Ts) > 1 else 0
+        batched = len(Ts) > 1 and step > 0 and step % 8 == 0 and not os.environ.get("DKD_NO_GRAM_BATCH") and all(
+            t.is_contiguous() and t.shape == Ts[0].shape and t.data_ptr() - Ts[0].data_ptr() == 2 * step * i for i, t in enumerate(Ts))
+        if batched:                 # the taps are slices of one tensor (deltakd_amd.vit allocates them so): ONE launch, a third of the atomics
+            ops.gram_batched(Ts[0], G, len(Ts), step, M=B * P, amap=smap)
+        else:
+            for i, T in enumerate(Ts):
+                ops.gram(T, G[i], M=B * P, amap=smap, mirror=False)     # upper-triangular tiles only
         _, hi, lo = self.right_vectors(G, rank, want_split=True)
         out = []
         for i, T in enumerate(Ts):

@@ -121,6 +121,15 @@ def gram(a, out, *, M=None, amap=IDENT, mirror=True):
     return out
 
 
+def gram_batched(a0, out, L, stride_a, *, M, amap=IDENT):
+    """out[l] (f32 [L, N, N], zero on entry) += A_l^T A_l for A_l = the bf16 [rows, N] matrix ``stride_a`` elements behind A_{l-1} (a0 = A_0):
+    the upper 128 x 128 tile pairs of all L matrices in one launch (include/dkd.h: dkd_gram_batched)."""
+    assert a0.dtype == BF16 and out.dtype == F32 and out.is_contiguous() and out.shape == (L, a0.shape[1], a0.shape[1])
+    N = a0.shape[1]
+    check(lib().dkd_gram_batched(ptr(a0), stride_a, ptr(out), N * N, L, M, N, a0.stride(0), N, amap, stream()), "gram_batched")
+    return out
+
+
 def gemm_tn_group(problems):
     """Up to four ``gemm_tn`` problems in one launch.  problems: sequence of dicts with the arguments of ``gemm_tn``
     (a, b, out and optionally M, N1, N2, amap, bmap, colsum)."""

@@ -638,11 +638,16 @@ def _blocks_forward_infer(x, B, N, model, scales, want):
         stats.zero_()
     taps = [None] * depth
     xp = x.data_ptr()
+    # the wanted taps are slices of ONE tensor, in block order: a consumer that reduces all of them (the LRKD Gram matrices) can do so in
+    # one batched launch (ops.gram_batched)
+    slab = torch.empty(len(want), M, D, device=dev, dtype=BF16) if want else None
+    nxt = 0
     for i in range(depth):
         bs = arr[i]
         bs.x = bs.x1 = bs.x2 = xp
         if i in want:
-            taps[i] = torch.empty(M, D, device=dev, dtype=BF16)
+            taps[i] = slab[nxt]
+            nxt += 1
             bs.tap = taps[i].data_ptr()
     # the activation slab / statistics buffers are reused from call to call: a call on ANOTHER stream than the previous one (a
     # teacher-stream prefetch followed by a main-stream fallback) first waits for that call's kernels

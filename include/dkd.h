@@ -116,6 +116,10 @@ int dkd_conv3x3_wgrad(const void* dY, const void* x, float* dW, float* dbias, in
  * touched -- the caller mirrors them (LRKD: G = T^T T of the teacher feature matrix, model/loss.py:318-321; 21 of 36 tiles for
  * N = 768). */
 int dkd_gram(const void* A, float* C, int32_t M, int32_t N, int32_t lda, int32_t ldc, DkdRowMap amap, void* stream);
+/* The same for L matrices of one shape at constant strides (elements) in ONE launch: A_l = A + l stride_a, C_l = C + l stride_c
+ * (C_l zero on entry).  The LRKD targets' three teacher taps (model/loss.py:318-324, blocks 0 / 1 / 11). */
+int dkd_gram_batched(const void* A, int64_t stride_a, float* C, int64_t stride_c, int32_t L, int32_t M, int32_t N, int32_t lda, int32_t ldc,
+                     DkdRowMap amap, void* stream);
 
 /* Up to 24 independent weight gradients in one launch (the two Linear layers of an MLP, proj + qkv, all four of a transformer block,
  * or those of several blocks): same arithmetic as dkd_gemm_tn per problem, but their blocks share the GPU -- every 128-column tile of

@@ -767,6 +767,28 @@ def test_mixup_also_writes_the_patch_matrix(ops, box):
         mp.undo()
 
 
+def test_gram_batched_equals_the_single_launches(ops):
+    """dkd_gram_batched: the upper tile pairs of L Gram matrices at constant strides in one launch == L calls of dkd_gram (row map
+    included: the prefix tokens of every sample are skipped), up to the atomics' summation order."""
+    L, Bn, N, D, npre = 3, 5, 30, 384, 2
+    from deltakd_amd.ffi import strip_map
+    slab = rnd(L, Bn * N, D, seed=77).to(BF16)
+    M = Bn * (N - npre)
+    smap = strip_map(N, npre)
+    one = torch.zeros(L, D, D, device=dev())
+    for l in range(L):
+        ops.gram(slab[l], one[l], M=M, amap=smap, mirror=False)
+    many = torch.zeros(L, D, D, device=dev())
+    ops.gram_batched(slab[0], many, L, slab.stride(0), M=M, amap=smap)
+    blk = torch.arange(D, device=dev()) // 128
+    upper = (blk[:, None] <= blk[None, :])[None].expand(L, D, D)
+    close(many[upper], one[upper], 1e-5, "batched Gram vs single launches")
+    ref = torch.stack([slab[l].view(Bn, N, D)[:, npre:].reshape(-1, D).float().t() @ slab[l].view(Bn, N, D)[:, npre:].reshape(-1, D).float()
+                       for l in range(L)])
+    close(many[upper], ref[upper], 1e-4, "batched Gram vs fp32 matmul")
+    assert int((many[~upper] != 0).sum()) == 0
+
+
 def test_lowrank_targets_vs_svd(ops):
     """Dt = 768 (subspace iteration + Rayleigh-Ritz path): U_k S_k against torch.linalg.svd on the host, up to column sign.
     Cold start, then a warm-started call on a different batch drawn from the same feature distribution."""

@@ -506,7 +506,10 @@ def main():
         out["other_configs"] = others
     if rank == 0:
         if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(cfg)
+            try:
+                out["cpu_baseline"] = cpu_baseline(cfg)
+            except Exception as e:              # the CPU leg must not lose the measured GPU line
+                out["cpu_baseline"] = {"value": None, "unit": "images/s", "cores": None, "kind": "port", "sample": f"failed: {type(e).__name__}: {e}"[:300]}
         print(json.dumps(out), flush=True)
     if world > 1 or force_dp:
         dist.destroy_process_group()
